@@ -1,0 +1,162 @@
+/*
+ * gsw_hip.h -- C ABI of the MI355X (gfx950) engine for the GSW hot path of n0900/tfhe.
+ *
+ * The reference crate has no FFI; the boundary these entry points replace is the Rust
+ * trait `FheScheme<R>` as implemented for `GSW<R, T>` (src/gsw/mod.rs:12-26,
+ * src/gsw/gsw_impl.rs:12-125).  A Rust shim implements that trait on top of this header
+ * (see INTEGRATION.md).  Every entry point below cites the reference lines it stands for.
+ *
+ * Element type.  The reference's `R: RingElement` (src/lib.rs:15-29) is `Fp`
+ * (src/field.rs:7-19, p = 2^31 - 1, stored in Montgomery form) or `Zpow2<M>`
+ * (src/pow2_ring.rs:14-16).  Across this ABI every element is its CANONICAL value in
+ * [0, q) as a uint32_t (`Into<u64>` of field.rs:52-56 / pow2_ring.rs:148-152, truncated).
+ * Zpow2<M> is supported for 1 <= M <= 32.
+ *
+ * Matrix forms.
+ *  - dense:    the reference's `Ciphertext = DMatrix<R>` (gsw_impl.rs:15), N x N with
+ *              N = ell * (n + 1), here ROW-MAJOR uint32 (nalgebra is column-major).
+ *  - compact:  Cc = BitDecomp^-1_linear(C), N rows x (n + 1) columns, row-major uint32
+ *              with leading dimension ld = gsw_ctx_ld() (n + 1 rounded up to 4); the
+ *              padding columns must be zero (every routine here keeps them zero).
+ *              BitDecomp(Cc) is the flattened ciphertext; the product of gsw_impl.rs:107
+ *              satisfies BitDecomp^-1_linear(C1 * C2) = C1 * C2c, which for a flattened
+ *              left operand is the binary x byte-limb contraction the MFMA kernel computes.
+ *  - prepared: the right operand re-laid out as signed byte-limb planes in MFMA fragment
+ *              order (opaque; size gsw_ctx_prepared_bytes()).
+ *
+ * All pointers named d_* are DEVICE pointers on the context's GPU.  Calls enqueue work on
+ * the context's stream and return; gsw_sync() waits.  Return value: 0 on success, else a
+ * GSW_E_* code with a message in gsw_last_error() (the shim turns these into the panics of
+ * the reference: gsw_impl.rs:69,88-89,105-106; error_sampling.rs:21; pk.rs:24-25).
+ * A context is thread-compatible (one thread at a time).
+ */
+#ifndef GSW_HIP_H
+#define GSW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSW_RING_FP_M31 0 /* Fp, field.rs:7-19                  */
+#define GSW_RING_ZPOW2 1  /* Zpow2<M>, pow2_ring.rs:14-16       */
+
+#define GSW_OK 0
+#define GSW_E_INVALID 1     /* bad argument / dimension mismatch */
+#define GSW_E_UNSUPPORTED 2 /* ring or operation not supported   */
+#define GSW_E_HIP 3         /* HIP runtime error                 */
+#define GSW_E_NOMEM 4       /* device allocation failed          */
+
+#define GSW_FLAG_NAND 1u /* out = G - G^-1(C1c) * C2c  (gsw_impl.rs:114-123 in compact form) */
+
+typedef struct gsw_ctx gsw_ctx;
+
+/* ---- context: stands for the `GSW<R, T> { n, m, .. }` value (gsw/mod.rs:29-38) ---- */
+int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int device);
+void gsw_ctx_destroy(gsw_ctx *ctx);
+const char *gsw_last_error(void);
+const char *gsw_version(void);
+/* use the caller's hipStream_t (e.g. the framework's current stream); NULL restores the context's own */
+int gsw_ctx_set_stream(gsw_ctx *ctx, void *hip_stream);
+int gsw_sync(gsw_ctx *ctx);
+int gsw_ctx_ell(const gsw_ctx *ctx);               /* R::Num_Bits (field.rs:39, pow2_ring.rs:19)   */
+int gsw_ctx_big_n(const gsw_ctx *ctx);             /* N = ell * (n + 1) (gsw_impl.rs:28)           */
+int gsw_ctx_ld(const gsw_ctx *ctx);                /* leading dimension of compact ciphertexts      */
+size_t gsw_ctx_compact_elems(const gsw_ctx *ctx);  /* N * ld uint32 per compact ciphertext          */
+size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx); /* bytes of one prepared right operand           */
+size_t gsw_ctx_rbits_elems(const gsw_ctx *ctx);    /* N * ld_r uint32 of packed encryption bits     */
+size_t gsw_ctx_pk_prepared_bytes(const gsw_ctx *ctx);
+/* upper bound, in bytes, of the scratch the batch entry points may allocate (default 2 GiB) */
+int gsw_ctx_set_workspace_limit(gsw_ctx *ctx, size_t bytes);
+/* per-kernel timing with HIP events on the context's stream: enable, then read the totals */
+int gsw_ctx_enable_timing(gsw_ctx *ctx, int enable);
+/* which: 0 = contraction kernel, 1 = right-operand preparation.  Waits for the stream. */
+int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launches);
+int gsw_ctx_reset_timing(gsw_ctx *ctx);
+
+/* ---- device memory helpers (plain hipMalloc / hipMemcpy on the context's GPU) ---- */
+int gsw_malloc(gsw_ctx *ctx, size_t bytes, void **d_ptr);
+int gsw_free(gsw_ctx *ctx, void *d_ptr);
+int gsw_memcpy_h2d(gsw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int gsw_memcpy_d2h(gsw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int gsw_memset_zero(gsw_ctx *ctx, void *d_dst, size_t bytes);
+/* host (rows x cols, row-major, tight) <-> device (rows x ld): pads / strips the leading dimension */
+int gsw_upload_compact(gsw_ctx *ctx, uint32_t *d_dst, const uint32_t *h_src);
+int gsw_download_compact(gsw_ctx *ctx, uint32_t *h_dst, const uint32_t *d_src);
+
+/* ---- gadget helpers (gsw/helper.rs) ---- */
+/* bit_decomp_matrix (helper.rs:7-21): d_in rows x cols (leading dim ld_in) -> d_out rows x cols*ell, tight */
+int gsw_bit_decomp(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, uint32_t *d_out);
+/* bit_decomp_inv_matrix (helper.rs:24-49): d_in rows x cols*ell tight -> d_out rows x cols (leading dim ld_out).
+ * quirk != 0 reproduces the reference (bit set iff entry == 1, then R::from); quirk == 0 is the linear inverse. */
+int gsw_bit_decomp_inv(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, uint32_t *d_out, int ld_out,
+                       int quirk);
+/* flatten_matrix (helper.rs:51-62), in place on a rows x cols*ell tight matrix */
+int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols);
+
+/* ---- FheScheme operations on dense N x N matrices (the reference's own form) ---- */
+/* add (gsw_impl.rs:87-94) and mult_const (gsw_impl.rs:97-101), elementwise over `count` elements;
+ * also valid on compact ciphertexts (count = gsw_ctx_compact_elems) */
+int gsw_add(gsw_ctx *ctx, const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_out, size_t count);
+int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t count);
+/* mult (gsw_impl.rs:104-111, default features) and nand (gsw_impl.rs:114-123): the plain
+ * dim x dim x dim product over R for arbitrary entries.  Parity path, not the throughput path. */
+int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
+int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
+
+/* ---- the hot path: Pc = G^-1(C1c) * C2c mod q on int8 MFMA (gsw_impl.rs:104-123 via the
+ *      identity above).  Strides are in uint32 elements between consecutive batch entries;
+ *      a stride of 0 reuses one operand for the whole batch. ---- */
+/* limb-split one or more compact right operands into prepared form */
+int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch);
+int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
+                            size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch,
+                            unsigned flags);
+/* same, preparing the right operands internally in workspace chunks */
+int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
+                         uint32_t *d_out, size_t stride_out, int batch, unsigned flags);
+
+/* ---- encrypt (gsw_impl.rs:27-42): compact form R * pk + message * G, the same contraction
+ *      with the N x m random bit matrix as the binary operand ---- */
+/* pk_matrix (pk.rs:28-38), m x (n + 1) row-major tight on the HOST -> prepared device form */
+int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepared);
+/* rnd_dmatrix(N, m, 0, 1) of gsw_impl.rs:30 as packed words (ell bits per word, word j of a row
+ * holds the bits for pk rows j*ell .. j*ell + ell - 1, little endian); host 0/1 bytes -> packed device */
+int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits /* N x m */, uint32_t *d_rbits);
+/* seeded device generator for the same matrix (uniform bits; the reference draws from rand::rng()) */
+int gsw_random_rbits(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_rbits, int batch);
+int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
+                      const uint32_t *d_messages /* batch values */, uint32_t *d_out, size_t stride_out, int batch);
+
+/* ---- decrypt (gsw_impl.rs:48-52) and mp_decrypt (gsw_impl.rs:67-84) on compact ciphertexts.
+ *      h_s is sk.s = (1, -t) (sk.rs:20-24) on the host; <C[i,:], v> = <Cc[i,:], s>. ---- */
+int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
+                      uint32_t *h_bits_out, uint32_t *h_raw_out /* may be NULL: <row ell-1, s> */);
+/* GSW_E_UNSUPPORTED for Fp, as the reference panics (gsw_impl.rs:68-70) */
+int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
+                         uint32_t *h_messages_out);
+/* d_out[i] = <d_mat[i, 0..cols), h_vec> mod q for i < rows (leading dimension ld): the matrix-vector
+ * products of keygen (b = B t, pk.rs:26) and of the key invariant pk_matrix * s = e (gsw_impl.rs:159) */
+int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, const uint32_t *h_vec,
+               uint32_t *d_out);
+/* dense-form decrypt: row ell-1 of C dotted with sk.v (gsw_impl.rs:48-52) */
+int gsw_decrypt_dense(gsw_ctx *ctx, const uint32_t *h_v, const uint32_t *d_c, uint32_t *h_bit_out);
+
+/* ---- sampling (error_sampling.rs) and digests ---- */
+/* rnd_ring_elm (error_sampling.rs:20-24): uniform in [min, max]; fails with GSW_E_INVALID when
+ * max > P unless `unchecked` (the reference asserts max <= P, which makes Zpow2<32> keygen panic) */
+int gsw_fill_uniform(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint64_t min, uint64_t max, int unchecked,
+                     uint32_t *d_out, size_t count);
+/* NaiveSampler (error_sampling.rs:73-84) and DiscrGaussianSampler (error_sampling.rs:32-71) */
+int gsw_sample_naive(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_out, size_t count);
+int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sigma, uint32_t *d_out, size_t count);
+/* 64-bit position-weighted digest of each batch entry (count uint32 each) */
+int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch,
+                     uint64_t *d_digests);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

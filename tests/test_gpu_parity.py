@@ -1,0 +1,367 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle on the
+same inputs -- bit exact (all arithmetic is integer) -- plus decrypt-after-operation.
+
+The reference holds no vectors for mult/nand/add/mult_const ("parity unpinned"): they are
+checked against the oracle's restatement of gsw_impl.rs:87-123 and by decryption.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P = 2147483647
+
+
+def _rings(oracle, tfhe_amd):
+    return {
+        "fp": (oracle.fp(), tfhe_amd.Fp()),
+        "z30": (oracle.zpow2(30), tfhe_amd.Zpow2(30)),
+        "z31": (oracle.zpow2(31), tfhe_amd.Zpow2(31)),
+        "z32": (oracle.zpow2(32), tfhe_amd.Zpow2(32)),
+        "z8": (oracle.zpow2(8), tfhe_amd.Zpow2(8)),
+    }
+
+
+@pytest.fixture(scope="module")
+def tfhe_amd():
+    import tfhe_amd as pkg
+    from tfhe_amd import _lib
+
+    _lib.lib()  # raises if libgsw_hip.so is missing: there is no fallback
+    return pkg
+
+
+def _rand_compact(rng, ring_o, n, batch=None):
+    shape = (ring_o.big_n(n), n + 1) if batch is None else (batch, ring_o.big_n(n), n + 1)
+    return rng.integers(0, ring_o.q, size=shape, dtype=np.uint64).astype(np.uint32)
+
+
+def _assert_equal(got, expect, what):
+    if not np.array_equal(got, expect):
+        bad = np.argwhere(got != expect)
+        raise AssertionError(f"{what}: {len(bad)} of {got.size} entries differ; first at {bad[0].tolist()}: "
+                             f"got {got[tuple(bad[0])]}, expect {expect[tuple(bad[0])]}")
+
+
+# ---------------------------------------------------------------- the hot path, small shapes
+@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 40), ("z30", 10), ("z31", 10),
+                                          ("z32", 10), ("z32", 33), ("z8", 5)])
+def test_mul_gadget_random_operands(oracle, tfhe_amd, ring_name, n, variant):
+    """Pc = BitDecomp(C1c) * C2c on uniform random operands (every bit pattern exercised)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    os.environ["GSW_GEMM_VARIANT"] = variant
+    try:
+        gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=1)
+    finally:
+        os.environ.pop("GSW_GEMM_VARIANT", None)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    rng = np.random.default_rng(100 + n)
+    c1, c2 = _rand_compact(rng, ring_o, n, 3), _rand_compact(rng, ring_o, n, 3)
+    c1[2] = ring_o.q - 1  # all-ones rows: the largest accumulators the shape allows
+    c2[2] = ring_o.q - 1
+    d1 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c1)
+    d2 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)
+    _assert_equal(d1.to_compact(), c1, "upload/download round trip")
+    got = gsw.mult(d1, d2).to_compact()
+    got_nand = gsw.nand(d1, d2).to_compact()
+    for b in range(3):
+        _assert_equal(got[b], og.mul_gadget(c1[b], c2[b]), f"mult[{b}] {ring_name} n={n}")
+        _assert_equal(got_nand[b], og.mul_gadget(c1[b], c2[b], flags=oracle.FLAG_NAND), f"nand[{b}] {ring_name} n={n}")
+
+
+def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
+    """Padding columns of the device layout stay zero; stride 0 broadcasts one right operand."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 10
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31)
+    og = oracle.GSW(ring_o, n, n * 31)
+    eng = gsw.engine
+    from tfhe_amd import _lib
+    rng = np.random.default_rng(7)
+    c1, c2 = _rand_compact(rng, ring_o, n, 4), _rand_compact(rng, ring_o, n)
+    d1 = tfhe_amd.Ciphertext.from_compact(eng, c1)
+    d2 = tfhe_amd.Ciphertext.from_compact(eng, c2)
+    out = tfhe_amd.Ciphertext(eng, 4)
+    _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, out.ptr, out.stride, 4, 0))
+    got = out.to_compact()
+    for b in range(4):
+        _assert_equal(got[b], og.mul_gadget(c1[b], c2), f"broadcast rhs [{b}]")
+    raw = out.buf.download(np.uint32, eng.compact_elems * 4).reshape(4, eng.big_n, eng.ld)
+    assert eng.ld == 12 and (raw[:, :, n + 1:] == 0).all()
+    # empty batch is a no-op
+    _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, out.ptr, out.stride, 0, 0))
+    with pytest.raises(tfhe_amd.GswError):
+        _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr + 4, d1.stride, d2.ptr, 0, out.ptr, out.stride,
+                                                   1, 0))
+
+
+def test_workspace_chunking(oracle, tfhe_amd):
+    """A batch larger than the workspace allows is processed in chunks with identical results."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 5
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31)
+    og = oracle.GSW(ring_o, n, n * 31)
+    from tfhe_amd import _lib
+    _lib.check(_lib.lib().gsw_ctx_set_workspace_limit(gsw.engine.handle, 2 * gsw.engine.prepared_bytes))
+    rng = np.random.default_rng(8)
+    c1, c2 = _rand_compact(rng, ring_o, n, 5), _rand_compact(rng, ring_o, n, 5)
+    got = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1),
+                   tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    _assert_equal(got, og.mul_gadget_batch(c1, c2), "chunked batch")
+
+
+# ---------------------------------------------------------------- scheme round trips
+@pytest.mark.parametrize("ring_name,n,sampler", [("fp", 10, "gaussian"), ("z30", 10, "gaussian"),
+                                                  ("z32", 6, "gaussian"), ("fp", 10, "naive")])
+def test_keygen_encrypt_decrypt(oracle, tfhe_amd, ring_name, n, sampler):
+    """gsw_impl.rs:165-186 (test_inputs) on the GPU engine, plus the key invariant of :150-163."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    m = n * ring_d.ell
+    gsw = tfhe_amd.GSW(ring_d, n, m, sampler=sampler, seed=42, check_max=(ring_name != "z32"))
+    sk, pk = gsw.keygen()
+    # pk_matrix * s == e: recompute e with the oracle and check it is a sample of the error distribution
+    e = oracle.matmul(ring_o, pk.pk_matrix, sk.s.reshape(-1, 1)).reshape(-1).astype(np.int64)
+    if sampler == "naive":
+        assert e.max() <= (P >> 15)
+    else:
+        centered = np.where(e > ring_o.q // 2, e - ring_o.q, e)
+        assert np.abs(centered).max() <= 14 and centered.std() > 0.5
+    for bit in (0, 1):
+        assert gsw.decrypt(sk, gsw.encrypt(pk, bit)) == bit
+    ct = gsw.encrypt_batch(pk, [1, 0, 1, 1, 0])
+    assert gsw.decrypt_batch(sk, ct).tolist() == [1, 0, 1, 1, 0]
+    # the reference-format dense matrix of the same ciphertext decrypts the same (gsw_impl.rs:48-52)
+    assert gsw.decrypt_dense(sk, ct.to_dense(0)) == 1
+    assert gsw.decrypt_dense(sk, ct.to_dense(1)) == 0
+
+
+def test_encrypt_matches_oracle(oracle, tfhe_amd):
+    """Batched encryption product R * pk + mu * G against the oracle, R given on the host."""
+    for ring_name, n in (("fp", 10), ("z32", 7)):
+        ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+        m = n * ring_d.ell
+        og = oracle.GSW(ring_o, n, m, seed=5, check_max=False)
+        sk, pk = og.keygen()
+        gsw = tfhe_amd.GSW(ring_d, n, m, seed=5, check_max=False)
+        dpk = gsw.make_pk(pk.pk_matrix[:, 1:], oracle.matmul(ring_o, pk.pk_matrix, sk.s.reshape(-1, 1)).reshape(-1),
+                          sk.t)
+        _assert_equal(dpk.pk_matrix, pk.pk_matrix, "pk_matrix = [B t + e | B]")
+        msgs = [0, 1, 12345 % ring_o.q]
+        rbits = np.stack([og.random_bits() for _ in msgs])
+        ct = gsw.encrypt_batch(dpk, msgs, rbits=rbits)
+        got = ct.to_compact()
+        for b, mu in enumerate(msgs):
+            _assert_equal(got[b], og.encrypt_compact(pk, mu, rbits[b]), f"encrypt[{b}] {ring_name}")
+        # dense form of the flattened ciphertext vs the oracle's bit_decomp
+        _assert_equal(ct.to_dense(1), oracle.bit_decomp_matrix(ring_o, got[1]), "to_dense")
+
+
+def test_device_random_bits_are_the_documented_stream(oracle, tfhe_amd):
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 4
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=77)
+    eng = gsw.engine
+    from tfhe_amd import _lib
+    buf = eng.alloc_u32(eng.rbits_elems * 2)
+    _lib.check(_lib.lib().gsw_random_rbits(eng.handle, 77, 3, buf.ptr, 2))
+    words = buf.download(np.uint32, eng.rbits_elems * 2).reshape(2, eng.big_n, n)
+    for (b, i, j) in [(0, 0, 0), (0, 5, 3), (1, 154, 2), (1, 0, 1)]:
+        expect = oracle.rng_u64(77, 3, (b * eng.big_n + i) * n + j) & 0x7FFFFFFF
+        assert int(words[b, i, j]) == expect
+    assert 0.49 < np.unpackbits(words.view(np.uint8)).mean() * 32 / 31 < 0.51
+
+
+def test_mp_decrypt(oracle, tfhe_amd):
+    """gsw_impl.rs:189-207: full-width messages over Zpow2<31>; Fp is refused like the reference."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["z31"]
+    gsw = tfhe_amd.GSW(ring_d, 10, 310, seed=3)
+    sk, pk = gsw.keygen()
+    msgs = oracle.fill_uniform(ring_o, 123, 0, 0, ring_o.max_u64() - 1, 6)
+    ct = gsw.encrypt_batch(pk, msgs)
+    assert gsw.mp_decrypt_batch(sk, ct).tolist() == msgs.tolist()
+    og = oracle.GSW(ring_o, 10, 310)
+    osk = oracle.SecretKey(sk.t, sk.s, sk.v)
+    assert og.mp_decrypt_compact(osk, ct.to_compact()[2]) == int(msgs[2])
+    fp = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62)
+    fsk, fpk = fp.keygen()
+    with pytest.raises(RuntimeError, match="Only supported for pow2 rings"):
+        fp.mp_decrypt(fsk, fp.encrypt(fpk, 1))
+
+
+def test_errors_mirror_the_reference_panics(tfhe_amd):
+    with pytest.raises(AssertionError, match="max <= P"):  # error_sampling.rs:21 via gsw_impl.rs:18
+        tfhe_amd.GSW(tfhe_amd.Zpow2(32), 4, 128).keygen()
+    g = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62)
+    with pytest.raises(ValueError, match="different sizes"):  # gsw_impl.rs:105-106
+        g.mult_dense(np.zeros((3, 3)), np.zeros((4, 4)))
+    with pytest.raises(ValueError, match="Dimension Mismatch"):  # pk.rs:24-25
+        g.make_pk(np.zeros((62, 2)), np.zeros(61), np.zeros(2))
+    with pytest.raises(tfhe_amd.GswError):
+        tfhe_amd.Engine(tfhe_amd.Zpow2(40), 2, 80)
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z30"])
+def test_decrypt_after_mul_and_nand(oracle, tfhe_amd, ring_name):
+    """Every product also decrypts to mu1 * mu2 (1 - mu1 * mu2 for NAND)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    n = 10
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=11)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    sk, pk = gsw.keygen()
+    mu1 = [0, 0, 1, 1]
+    mu2 = [0, 1, 0, 1]
+    c1, c2 = gsw.encrypt_batch(pk, mu1), gsw.encrypt_batch(pk, mu2)
+    prod, nand = gsw.mult(c1, c2), gsw.nand(c1, c2)
+    assert gsw.decrypt_batch(sk, prod).tolist() == [a * b for a, b in zip(mu1, mu2)]
+    assert gsw.decrypt_batch(sk, nand).tolist() == [1 - a * b for a, b in zip(mu1, mu2)]
+    h1, h2 = c1.to_compact(), c2.to_compact()
+    _assert_equal(prod.to_compact(), og.mul_gadget_batch(h1, h2), "product of real ciphertexts")
+    # the dense product of the flattened operands is the same ciphertext (gsw_impl.rs:107)
+    dense = gsw.mult_dense(c1.to_dense(3), c2.to_dense(3))
+    _assert_equal(gsw.bit_decomp_inv_matrix(dense, quirk=False), prod.to_compact()[3], "dense vs compact product")
+    # add (gsw_impl.rs:87-94) and mult_const (gsw_impl.rs:97-101) in compact form
+    s = gsw.add(c1, c2)
+    _assert_equal(s.to_compact(), og.add(h1.reshape(4, -1), h2.reshape(4, -1)).reshape(h1.shape), "add")
+    gsw.mult_const(s, 3)
+    _assert_equal(s.to_compact(), og.mult_const(og.add(h1.reshape(4, -1), h2.reshape(4, -1)), 3).reshape(h1.shape),
+                  "mult_const")
+
+
+def test_depth8_chain_noise(oracle, tfhe_amd):
+    """acc <- mult(acc, fresh_i), depth 8, sigma = 1: the product stays decryptable and the noise of
+    row ell-1 stays far below q/4 (additive growth with the accumulator as the decomposed operand)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 10
+    gsw = tfhe_amd.GSW(ring_d, n, 310, seed=2025)
+    og = oracle.GSW(ring_o, n, 310)
+    sk, pk = gsw.keygen()
+    osk = oracle.SecretKey(sk.t, sk.s, sk.v)
+    for msgs in ([1] * 9, [1, 1, 1, 0, 1, 1, 1, 1, 1]):
+        fresh = gsw.encrypt_batch(pk, msgs)
+        host = fresh.to_compact()
+        acc = tfhe_amd.Ciphertext.from_compact(gsw.engine, host[0])
+        acc_o, want = host[0], msgs[0]
+        for i in range(1, 9):
+            acc = gsw.mult(acc, tfhe_amd.Ciphertext.from_compact(gsw.engine, host[i]))
+            acc_o = og.mul_gadget(acc_o, host[i])
+            want *= msgs[i]
+            assert gsw.decrypt(sk, acc) == want
+        _assert_equal(acc.to_compact(), acc_o, "depth-8 chain")
+        noise = og.noise(osk, acc_o, want)
+        assert noise < 20000 < ring_o.q // 4, noise  # ~ 8 * sqrt(N/2) * sqrt(m/2) = 1.3e3 expected
+
+
+# ---------------------------------------------------------------- dense reference-format operations
+@pytest.mark.parametrize("ring_name", ["fp", "z32", "z8"])
+def test_dense_ops_arbitrary_entries(oracle, tfhe_amd, ring_name):
+    """mult/nand/add/mult_const of gsw_impl.rs:87-123 on arbitrary N x N matrices, and the gadget
+    helpers of helper.rs including the `== 1` quirk of bit_decomp_inv."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    n = 2
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    dim = ring_o.big_n(n) + 5  # not a multiple of the 16 x 16 tile
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
+    _assert_equal(gsw.mult_dense(a, b), og.mult(a, b), "mult_dense")
+    _assert_equal(gsw.nand_dense(a, b), og.nand(a, b), "nand_dense")
+    _assert_equal(gsw.add_dense(a, b), og.add(a, b), "add_dense")
+    _assert_equal(gsw.mult_const_dense(a, ring_o.q - 2), og.mult_const(a, ring_o.q - 2), "mult_const_dense")
+    comp = rng.integers(0, ring_o.q, size=(7, 5), dtype=np.uint64).astype(np.uint32)
+    bits = gsw.bit_decomp_matrix(comp)
+    _assert_equal(bits, oracle.bit_decomp_matrix(ring_o, comp), "bit_decomp")
+    _assert_equal(gsw.bit_decomp_inv_matrix(bits), comp, "bit_decomp_inv round trip")
+    small = rng.integers(0, 4, size=(7, 5 * ring_o.ell), dtype=np.uint64).astype(np.uint32)  # entries 0..3
+    _assert_equal(gsw.bit_decomp_inv_matrix(small, quirk=True), oracle.bit_decomp_inv_matrix(ring_o, small, True),
+                  "bit_decomp_inv quirk")
+    _assert_equal(gsw.bit_decomp_inv_matrix(small, quirk=False), oracle.bit_decomp_inv_matrix(ring_o, small, False),
+                  "bit_decomp_inv linear")
+    _assert_equal(gsw.flatten_matrix(small), oracle.flatten_matrix(ring_o, small), "flatten")
+    ones = np.ones((1, ring_o.ell), dtype=np.uint32)
+    assert gsw.bit_decomp_inv_matrix(ones)[0, 0] == oracle.bit_decomp_inv_matrix(ring_o, ones)[0, 0]
+
+
+def test_samplers_and_digest(oracle, tfhe_amd):
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    gsw = tfhe_amd.GSW(ring_d, 2, 62, seed=9)
+    eng = gsw.engine
+    from tfhe_amd import _lib
+    L = _lib.lib()
+    count = 200000
+    buf = eng.alloc_u32(count)
+    _lib.check(L.gsw_fill_uniform(eng.handle, 9, 4, 5, P - 1, 0, buf.ptr, count))
+    _assert_equal(buf.download(np.uint32, count), oracle.fill_uniform(ring_o, 9, 4, 5, P - 1, count), "uniform")
+    _lib.check(L.gsw_sample_naive(eng.handle, 9, 5, buf.ptr, count))
+    _assert_equal(buf.download(np.uint32, count), oracle.sample_naive(ring_o, 9, 5, count), "naive sampler")
+    _lib.check(L.gsw_sample_gaussian(eng.handle, 9, 6, 1.0, buf.ptr, count))
+    g = buf.download(np.uint32, count).astype(np.int64)
+    g = np.where(g > P // 2, g - P, g).astype(np.float64)
+    assert abs(g.mean()) < 0.02 and abs(g.var() - 1.0) < 0.03 and np.abs(g).max() <= 14
+    _lib.check(L.gsw_sample_gaussian(eng.handle, 9, 7, 3.2, buf.ptr, count))
+    g = buf.download(np.uint32, count).astype(np.int64)
+    g = np.where(g > P // 2, g - P, g).astype(np.float64)
+    assert abs(g.var() - 3.2 ** 2) < 0.4
+    with pytest.raises(tfhe_amd.GswError):
+        _lib.check(L.gsw_fill_uniform(eng.handle, 9, 4, 0, 2 ** 32 - 1, 0, buf.ptr, 4))
+    x = oracle.fill_uniform(ring_o, 1, 1, 0, P - 1, 3 * 1000).reshape(3, 1000)
+    buf.upload(x)
+    dig = eng.alloc(8 * 3)
+    _lib.check(L.gsw_digest_batch(eng.handle, buf.ptr, 1000, 1000, 3, dig.ptr))
+    assert dig.download(np.uint64, 3).tolist() == [oracle.digest(x[b]) for b in range(3)]
+
+
+# ---------------------------------------------------------------- benchmark shapes
+def _sampled_rows_check(oracle, og, c1, c2, got, rows, what, flags=0):
+    for r in rows:
+        expect = og.mul_gadget_rows(c1, c2, int(r), 1, flags)[0]
+        _assert_equal(got[r], expect, f"{what} row {r}")
+
+
+@pytest.mark.parametrize("ring_name,n", [("fp", 256), ("fp", 512), ("z32", 512)])
+def test_benchmark_shapes_sampled_rows_and_linearity(oracle, tfhe_amd, ring_name, n):
+    """n = 256 / 512 (N = 7967 / 15903 / 16416): sampled output rows against the oracle (each row is
+    an independent dot-product family), the first and last row tiles included, plus the
+    size-independent property mult(C1, X + Y) = mult(C1, X) + mult(C1, Y) on the whole matrix."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    big_n = ring_o.big_n(n)
+    rng = np.random.default_rng(n)
+    c1, x, y = (_rand_compact(rng, ring_o, n) for _ in range(3))
+    d1 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c1)
+    dx = tfhe_amd.Ciphertext.from_compact(gsw.engine, x)
+    dy = tfhe_amd.Ciphertext.from_compact(gsw.engine, y)
+    px = gsw.mult(d1, dx)
+    got = px.to_compact()
+    rows = np.unique(np.concatenate([[0, 1, 31, 32, 255, 256, big_n - 1, big_n - 2, big_n - 32],
+                                     rng.integers(0, big_n, size=24)]))
+    _sampled_rows_check(oracle, og, c1, x, got, rows, f"{ring_name} n={n}")
+    lhs = gsw.mult(d1, gsw.add(dx, dy)).to_compact()
+    rhs = gsw.add(px, gsw.mult(d1, dy)).to_compact()
+    _assert_equal(lhs, rhs, "linearity in the right operand")
+    nand = gsw.nand(d1, dx).to_compact()
+    _sampled_rows_check(oracle, og, c1, x, nand, rows[:6], f"nand {ring_name} n={n}", oracle.FLAG_NAND)
+
+
+def test_n256_full_product_and_decrypt_after_mul(oracle, tfhe_amd):
+    """One full n = 256 product against the oracle (every entry), and decrypt-after-mul on a small
+    batch of real encryptions under a real key at that size."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 256
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=256)
+    og = oracle.GSW(ring_o, n, n * 31)
+    sk, pk = gsw.keygen()
+    mu1, mu2 = [1, 1, 0, 1], [1, 0, 1, 1]
+    c1, c2 = gsw.encrypt_batch(pk, mu1), gsw.encrypt_batch(pk, mu2)
+    assert gsw.decrypt_batch(sk, c1).tolist() == mu1
+    prod = gsw.mult(c1, c2)
+    assert gsw.decrypt_batch(sk, prod).tolist() == [a * b for a, b in zip(mu1, mu2)]
+    assert gsw.decrypt_batch(sk, gsw.nand(c1, c2)).tolist() == [1 - a * b for a, b in zip(mu1, mu2)]
+    h1, h2, hp = c1.to_compact(), c2.to_compact(), prod.to_compact()
+    _assert_equal(hp[0], og.mul_gadget(h1[0], h2[0]), "full n=256 product")
+    osk = oracle.SecretKey(sk.t, sk.s, sk.v)
+    assert og.noise(osk, hp[0], 1) < ring_o.q // 4 // 1000

@@ -1,0 +1,103 @@
+"""ctypes binding of the C-ABI library (include/gsw_hip.h).
+
+The product path has no CPU fallback: if `libgsw_hip.so` is missing or a symbol cannot be
+resolved, importing this module's `lib()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsw_hip.so")
+
+RING_FP_M31 = 0
+RING_ZPOW2 = 1
+FLAG_NAND = 1
+
+OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_NOMEM = 0, 1, 2, 3, 4
+
+_vp, _sz, _i, _u32, _u64, _dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+
+# every symbol include/gsw_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "gsw_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "gsw_ctx_destroy": (None, [_vp]),
+    "gsw_last_error": (C.c_char_p, []),
+    "gsw_version": (C.c_char_p, []),
+    "gsw_ctx_set_stream": (_i, [_vp, _vp]),
+    "gsw_sync": (_i, [_vp]),
+    "gsw_ctx_ell": (_i, [_vp]),
+    "gsw_ctx_big_n": (_i, [_vp]),
+    "gsw_ctx_ld": (_i, [_vp]),
+    "gsw_ctx_compact_elems": (_sz, [_vp]),
+    "gsw_ctx_prepared_bytes": (_sz, [_vp]),
+    "gsw_ctx_rbits_elems": (_sz, [_vp]),
+    "gsw_ctx_pk_prepared_bytes": (_sz, [_vp]),
+    "gsw_ctx_set_workspace_limit": (_i, [_vp, _sz]),
+    "gsw_ctx_enable_timing": (_i, [_vp, _i]),
+    "gsw_ctx_kernel_time": (_i, [_vp, _i, C.POINTER(_dbl), C.POINTER(C.c_long)]),
+    "gsw_ctx_reset_timing": (_i, [_vp]),
+    "gsw_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "gsw_free": (_i, [_vp, _vp]),
+    "gsw_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "gsw_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "gsw_memset_zero": (_i, [_vp, _vp, _sz]),
+    "gsw_upload_compact": (_i, [_vp, _vp, _vp]),
+    "gsw_download_compact": (_i, [_vp, _vp, _vp]),
+    "gsw_bit_decomp": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gsw_bit_decomp_inv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
+    "gsw_flatten": (_i, [_vp, _vp, _i, _i]),
+    "gsw_add": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "gsw_mult_const": (_i, [_vp, _vp, _u32, _sz]),
+    "gsw_mul_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "gsw_nand_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
+    "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
+    "gsw_mul_gadget_batch": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
+    "gsw_prepare_pk": (_i, [_vp, _vp, _vp]),
+    "gsw_pack_rbits": (_i, [_vp, _vp, _vp]),
+    "gsw_random_rbits": (_i, [_vp, _u64, _u64, _vp, _i]),
+    "gsw_encrypt_batch": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _i]),
+    "gsw_decrypt_batch": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp]),
+    "gsw_mp_decrypt_batch": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "gsw_matvec": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "gsw_decrypt_dense": (_i, [_vp, _vp, _vp, _vp]),
+    "gsw_fill_uniform": (_i, [_vp, _u64, _u64, _u64, _u64, _i, _vp, _sz]),
+    "gsw_sample_naive": (_i, [_vp, _u64, _u64, _vp, _sz]),
+    "gsw_sample_gaussian": (_i, [_vp, _u64, _u64, _dbl, _vp, _sz]),
+    "gsw_digest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _vp]),
+}
+
+_lib = None
+
+
+class GswError(RuntimeError):
+    """A non-zero status from the engine (the Rust shim turns these into the reference's panics)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"gsw error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the engine has no CPU fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != OK:
+        raise GswError(code, lib().gsw_last_error().decode())

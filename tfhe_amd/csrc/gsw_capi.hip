@@ -1,0 +1,703 @@
+// C ABI of the engine (include/gsw_hip.h): context, device memory helpers, argument checks and
+// the batch schedulers in front of the gfx950 kernels.  No CPU fallback exists: every operation
+// either runs its HIP kernel or returns an error.
+#include "../../include/gsw_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gsw_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? GSW_E_NOMEM : GSW_E_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct gsw_ctx {
+    gswk::RingDesc ring;
+    int n, m;
+    int big_n;   // ell * (n + 1)
+    int width;   // n + 1
+    int ld;      // width rounded up to 4
+    int words;   // ceil(m / ell): packed words per row of the encryption bit matrix
+    int ld_r;    // words rounded up to 4
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    void *ws;
+    size_t ws_bytes;
+    size_t ws_limit;
+    int gemm_variant;
+    bool timing;
+    std::vector<TimedLaunch> timed[2];
+};
+
+namespace {
+
+int use_device(const gsw_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return GSW_OK;
+}
+
+int ensure_workspace(gsw_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return GSW_OK;
+    if (ctx->ws) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return GSW_OK;
+}
+
+struct ScopedTimer {
+    gsw_ctx *ctx;
+    int which;
+    TimedLaunch t{};
+    bool on;
+    ScopedTimer(gsw_ctx *c, int w) : ctx(c), which(w), on(c->timing) {
+        if (on) {
+            if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) on = false;
+            else hipEventRecord(t.start, ctx->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            hipEventRecord(t.stop, ctx->stream);
+            ctx->timed[which].push_back(t);
+        }
+    }
+};
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// checks shared by the two contraction entry points
+int check_gemm_common(const gsw_ctx *ctx, const void *lhs, size_t stride1, const void *out, size_t stride_out,
+                      int batch, unsigned flags) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (batch < 0) return fail(GSW_E_INVALID, "negative batch");
+    if (flags & ~GSW_FLAG_NAND) return fail(GSW_E_INVALID, "unknown flags 0x%x", flags);
+    if (batch == 0) return GSW_OK;
+    if (!lhs || !out) return fail(GSW_E_INVALID, "null operand");
+    if (!aligned16(lhs) || (stride1 & 3u)) return fail(GSW_E_INVALID, "left operand must be 16-byte aligned with a stride multiple of 4");
+    if (!aligned16(out)) return fail(GSW_E_INVALID, "output must be 16-byte aligned");
+    if (stride_out < gsw_ctx_compact_elems(ctx) && batch > 1)
+        return fail(GSW_E_INVALID, "output stride %zu smaller than one ciphertext (%zu)", stride_out,
+                    gsw_ctx_compact_elems(ctx));
+    return GSW_OK;
+}
+
+int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &a) {
+    ScopedTimer timer(ctx, 0);
+    HIP_TRY(gswk::launch_gemm(ctx->ring, a, ctx->gemm_variant, ctx->stream));
+    return GSW_OK;
+}
+
+int run_prepare(gsw_ctx *ctx, const gswk::PrepArgs &a) {
+    ScopedTimer timer(ctx, 1);
+    HIP_TRY(gswk::launch_prepare(ctx->ring, a, ctx->stream));
+    return GSW_OK;
+}
+
+// cumulative table of the discrete Gaussian P(k) ~ exp(-k^2 / (2 sigma^2)), k in [-kmax, kmax]
+void gaussian_table(double sigma, std::vector<uint64_t> &cum, int &kmax) {
+    kmax = (int)std::ceil(13.0 * sigma) + 1;
+    if (kmax > 4096) kmax = 4096;
+    const int len = 2 * kmax + 1;
+    cum.resize(len);
+    long double total = 0.0L;
+    for (int k = -kmax; k <= kmax; ++k) total += expl(-(long double)k * k / (2.0L * sigma * sigma));
+    long double run = 0.0L;
+    for (int idx = 0; idx < len; ++idx) {
+        const int k = idx - kmax;
+        run += expl(-(long double)k * k / (2.0L * sigma * sigma)) / total;
+        const long double scaled = run * 18446744073709551616.0L;
+        cum[idx] = scaled >= 18446744073709551615.0L ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)scaled;
+    }
+    cum[len - 1] = 0xFFFFFFFFFFFFFFFFull;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gsw_last_error(void) { return g_last_error.c_str(); }
+const char *gsw_version(void) { return "gsw-mi355x 0.1 (gfx950)"; }
+
+int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int device) {
+    if (!out) return fail(GSW_E_INVALID, "null output pointer");
+    *out = nullptr;
+    gswk::RingDesc ring{};
+    if (ring_kind == GSW_RING_FP_M31) {
+        ring = {gswk::kRingFp, 31, gswk::kFpP};  // field.rs:8,39
+    } else if (ring_kind == GSW_RING_ZPOW2) {
+        if (log2q < 1 || log2q > 32)
+            return fail(GSW_E_UNSUPPORTED, "Zpow2<%d>: only 1 <= M <= 32 is supported", log2q);
+        ring = {gswk::kRingZpow2, log2q, log2q == 32 ? 0xFFFFFFFFu : ((1u << log2q) - 1u)};  // pow2_ring.rs:39-48
+    } else {
+        return fail(GSW_E_UNSUPPORTED, "unknown ring kind %d", ring_kind);
+    }
+    if (n < 1 || m < 1) return fail(GSW_E_INVALID, "n and m must be positive (n=%d, m=%d)", n, m);
+    if ((long)ring.ell * (n + 1) > (1L << 20)) return fail(GSW_E_INVALID, "n=%d too large", n);
+    if (m > (1 << 24)) return fail(GSW_E_INVALID, "m=%d too large", m);
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(GSW_E_INVALID, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    gsw_ctx *ctx = new gsw_ctx();
+    ctx->ring = ring;
+    ctx->n = n;
+    ctx->m = m;
+    ctx->big_n = ring.ell * (n + 1);
+    ctx->width = n + 1;
+    ctx->ld = (n + 1 + 3) & ~3;
+    ctx->words = (m + ring.ell - 1) / ring.ell;
+    ctx->ld_r = (ctx->words + 3) & ~3;
+    ctx->device = device;
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    ctx->ws_limit = (size_t)2 << 30;
+    ctx->gemm_variant = 0;
+    ctx->timing = false;
+    if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(GSW_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return GSW_OK;
+}
+
+void gsw_ctx_destroy(gsw_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &v : ctx->timed)
+        for (auto &t : v) {
+            (void)hipEventDestroy(t.start);
+            (void)hipEventDestroy(t.stop);
+        }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int gsw_ctx_set_stream(gsw_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return GSW_OK;
+}
+
+int gsw_sync(gsw_ctx *ctx) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_ctx_ell(const gsw_ctx *ctx) { return ctx ? ctx->ring.ell : 0; }
+int gsw_ctx_big_n(const gsw_ctx *ctx) { return ctx ? ctx->big_n : 0; }
+int gsw_ctx_ld(const gsw_ctx *ctx) { return ctx ? ctx->ld : 0; }
+size_t gsw_ctx_compact_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld : 0; }
+size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld) : 0; }
+size_t gsw_ctx_rbits_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld_r : 0; }
+size_t gsw_ctx_pk_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld_r) : 0; }
+
+int gsw_ctx_set_workspace_limit(gsw_ctx *ctx, size_t bytes) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (bytes < gsw_ctx_prepared_bytes(ctx))
+        return fail(GSW_E_INVALID, "workspace limit below one prepared operand (%zu bytes)", gsw_ctx_prepared_bytes(ctx));
+    ctx->ws_limit = bytes;
+    return GSW_OK;
+}
+
+int gsw_ctx_enable_timing(gsw_ctx *ctx, int enable) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    ctx->timing = enable != 0;
+    return GSW_OK;
+}
+
+int gsw_ctx_reset_timing(gsw_ctx *ctx) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &v : ctx->timed) {
+        for (auto &t : v) {
+            (void)hipEventDestroy(t.start);
+            (void)hipEventDestroy(t.stop);
+        }
+        v.clear();
+    }
+    return GSW_OK;
+}
+
+int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launches) {
+    if (!ctx || which < 0 || which > 1 || !total_ms || !launches) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (auto &t : ctx->timed[which]) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+        total += ms;
+    }
+    *total_ms = total;
+    *launches = (long)ctx->timed[which].size();
+    return GSW_OK;
+}
+
+// ---- device memory helpers ----
+
+int gsw_malloc(gsw_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    *d_ptr = nullptr;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return GSW_OK;
+}
+
+int gsw_free(gsw_ctx *ctx, void *d_ptr) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return GSW_OK;
+}
+
+int gsw_memcpy_h2d(gsw_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_memcpy_d2h(gsw_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_memset_zero(gsw_ctx *ctx, void *d_dst, size_t bytes) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_upload_compact(gsw_ctx *ctx, uint32_t *d_dst, const uint32_t *h_src) {
+    if (!ctx || !d_dst || !h_src) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(d_dst, 0, gsw_ctx_compact_elems(ctx) * 4, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(d_dst, (size_t)ctx->ld * 4, h_src, (size_t)ctx->width * 4, (size_t)ctx->width * 4,
+                             (size_t)ctx->big_n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_download_compact(gsw_ctx *ctx, uint32_t *h_dst, const uint32_t *d_src) {
+    if (!ctx || !h_dst || !d_src) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipMemcpy2DAsync(h_dst, (size_t)ctx->width * 4, d_src, (size_t)ctx->ld * 4, (size_t)ctx->width * 4,
+                             (size_t)ctx->big_n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GSW_OK;
+}
+
+// ---- gadget helpers ----
+
+int gsw_bit_decomp(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, uint32_t *d_out) {
+    if (!ctx || !d_in || !d_out || rows < 0 || cols < 0 || ld_in < cols) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, d_in, rows, cols, ld_in, d_out, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_bit_decomp_inv(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, uint32_t *d_out, int ld_out,
+                       int quirk) {
+    if (!ctx || !d_in || !d_out || rows < 0 || cols < 0 || ld_out < cols) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_bit_decomp_inv(ctx->ring, d_in, rows, cols, d_out, ld_out, quirk, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols) {
+    if (!ctx || !d_mat || rows < 0 || cols < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    // helper.rs:51-54: bit_decomp_inv then bit_decomp, through a rows x cols scratch matrix
+    uint32_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, (size_t)rows * cols * 4 + 16));
+    hipError_t e = gswk::launch_bit_decomp_inv(ctx->ring, d_mat, rows, cols, tmp, cols, 1, ctx->stream);
+    if (e == hipSuccess) e = gswk::launch_bit_decomp(ctx->ring, tmp, rows, cols, cols, d_mat, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    return GSW_OK;
+}
+
+// ---- elementwise and dense operations ----
+
+int gsw_add(gsw_ctx *ctx, const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_out, size_t count) {
+    if (!ctx || !d_a || !d_b || !d_out) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_add(ctx->ring, d_a, d_b, d_out, count, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t count) {
+    if (!ctx || !d_inout) return fail(GSW_E_INVALID, "bad argument");
+    if (ctx->ring.kind == gswk::kRingFp ? constant >= gswk::kFpP : (constant & ~ctx->ring.mask) != 0)
+        return fail(GSW_E_INVALID, "constant %u is not a canonical ring element", constant);
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_mult_const(ctx->ring, d_inout, constant, count, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim) {
+    if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_mul_dense(ctx->ring, d_c1, d_c2, d_out, dim, 0, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim) {
+    if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_mul_dense(ctx->ring, d_c1, d_c2, d_out, dim, 1, ctx->stream));
+    return GSW_OK;
+}
+
+// ---- the hot path ----
+
+int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch) {
+    if (!ctx || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (batch == 0) return GSW_OK;
+    if (!d_c2c || !d_prepared || !aligned16(d_prepared)) return fail(GSW_E_INVALID, "null or unaligned operand");
+    if (int rc = use_device(ctx)) return rc;
+    gswk::PrepArgs a{};
+    a.src = d_c2c;
+    a.src_stride = stride_c2c;
+    a.dst = (uint8_t *)d_prepared;
+    a.dst_stride = gsw_ctx_prepared_bytes(ctx);
+    a.rows_valid = ctx->big_n;
+    a.cols_valid = ctx->width;
+    a.ld_src = ctx->ld;
+    a.elems = ctx->width;
+    a.e4 = ctx->ld;
+    a.batch = batch;
+    return run_prepare(ctx, a);
+}
+
+int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
+                            size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch,
+                            unsigned flags) {
+    if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
+    if (batch == 0) return GSW_OK;
+    if (!d_prepared || !aligned16(d_prepared) || (stride_prepared_bytes & 15u))
+        return fail(GSW_E_INVALID, "prepared operand must be 16-byte aligned");
+    if (int rc = use_device(ctx)) return rc;
+    gswk::GemmArgs a{};
+    a.lhs = d_c1c;
+    a.lhs_stride = stride1;
+    a.rhs = (const uint8_t *)d_prepared;
+    a.rhs_stride = stride_prepared_bytes;
+    a.out = d_out;
+    a.out_stride = stride_out;
+    a.addend = nullptr;
+    a.rows = ctx->big_n;
+    a.e4 = ctx->ld;
+    a.ld_lhs = ctx->ld;
+    a.out_cols = ctx->width;
+    a.ld_out = ctx->ld;
+    a.batch = batch;
+    a.mode = (flags & GSW_FLAG_NAND) ? gswk::kModeNand : gswk::kModeMul;
+    return run_gemm(ctx, a);
+}
+
+int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
+                         uint32_t *d_out, size_t stride_out, int batch, unsigned flags) {
+    if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
+    if (batch == 0) return GSW_OK;
+    if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
+    if (int rc = use_device(ctx)) return rc;
+    const size_t prep = gsw_ctx_prepared_bytes(ctx);
+    // a shared right operand (stride 0) is prepared once; otherwise work in workspace-sized chunks
+    const bool shared = stride2 == 0;
+    size_t chunk = shared ? 1 : ctx->ws_limit / prep;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)batch) chunk = (size_t)batch;
+    if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
+    if (shared) {
+        if (int rc = gsw_prepare_rhs(ctx, d_c2c, 0, ctx->ws, 1)) return rc;
+        return gsw_mul_gadget_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags);
+    }
+    for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
+        const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
+        if (int rc = gsw_prepare_rhs(ctx, d_c2c + b0 * stride2, stride2, ctx->ws, cur)) return rc;
+        if (int rc = gsw_mul_gadget_prepared(ctx, d_c1c + b0 * stride1, stride1, ctx->ws, prep,
+                                             d_out + b0 * stride_out, stride_out, cur, flags))
+            return rc;
+    }
+    return GSW_OK;
+}
+
+// ---- encrypt ----
+
+int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepared) {
+    if (!ctx || !h_pk_matrix || !d_pk_prepared || !aligned16(d_pk_prepared)) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    // stage pk_matrix (m x (n+1), pk.rs:28-38) on the device with the padded leading dimension
+    const size_t bytes = (size_t)ctx->m * ctx->ld * 4;
+    uint32_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, bytes + 16));
+    hipError_t e = hipMemsetAsync(tmp, 0, bytes, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(tmp, (size_t)ctx->ld * 4, h_pk_matrix, (size_t)ctx->width * 4, (size_t)ctx->width * 4,
+                             (size_t)ctx->m, hipMemcpyHostToDevice, ctx->stream);
+    int rc = GSW_OK;
+    if (e == hipSuccess) {
+        gswk::PrepArgs a{};
+        a.src = tmp;
+        a.src_stride = 0;
+        a.dst = (uint8_t *)d_pk_prepared;
+        a.dst_stride = gsw_ctx_pk_prepared_bytes(ctx);
+        a.rows_valid = ctx->m;
+        a.cols_valid = ctx->width;
+        a.ld_src = ctx->ld;
+        a.elems = ctx->words;
+        a.e4 = ctx->ld_r;
+        a.batch = 1;
+        rc = run_prepare(ctx, a);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    return rc;
+}
+
+int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits, uint32_t *d_rbits) {
+    if (!ctx || !h_bits || !d_rbits) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    const int ell = ctx->ring.ell, words = ctx->words;
+    std::vector<uint32_t> packed((size_t)ctx->big_n * ctx->ld_r, 0u);
+    for (int i = 0; i < ctx->big_n; ++i)
+        for (int j = 0; j < words; ++j) {
+            uint32_t w = 0;
+            for (int k = 0; k < ell && j * ell + k < ctx->m; ++k) {
+                const uint8_t bit = h_bits[(size_t)i * ctx->m + (size_t)j * ell + k];
+                if (bit > 1) return fail(GSW_E_INVALID, "encryption bits must be 0 or 1");
+                w |= (uint32_t)bit << k;
+            }
+            packed[(size_t)i * ctx->ld_r + j] = w;
+        }
+    return gsw_memcpy_h2d(ctx, d_rbits, packed.data(), packed.size() * 4);
+}
+
+int gsw_random_rbits(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_rbits, int batch) {
+    if (!ctx || !d_rbits || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_random_words(seed, stream, d_rbits, ctx->big_n, ctx->words, ctx->ld_r, ctx->ring.ell,
+                                      ctx->m - (ctx->words - 1) * ctx->ring.ell, batch, gsw_ctx_rbits_elems(ctx),
+                                      ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
+                      const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, int batch) {
+    if (int rc = check_gemm_common(ctx, d_rbits, stride_rbits, d_out, stride_out, batch, 0)) return rc;
+    if (batch == 0) return GSW_OK;
+    if (!d_pk_prepared || !aligned16(d_pk_prepared) || !d_messages) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    gswk::GemmArgs a{};
+    a.lhs = d_rbits;
+    a.lhs_stride = stride_rbits;
+    a.rhs = (const uint8_t *)d_pk_prepared;
+    a.rhs_stride = 0;  // one public key for the whole batch
+    a.out = d_out;
+    a.out_stride = stride_out;
+    a.addend = d_messages;
+    a.rows = ctx->big_n;
+    a.e4 = ctx->ld_r;
+    a.ld_lhs = ctx->ld_r;
+    a.out_cols = ctx->width;
+    a.ld_out = ctx->ld;
+    a.batch = batch;
+    a.mode = gswk::kModeEncrypt;
+    return run_gemm(ctx, a);
+}
+
+// ---- decrypt ----
+
+static int row_dots(gsw_ctx *ctx, const uint32_t *h_vec, int cols, const uint32_t *d_x, size_t stride, int ld,
+                    int row0, int nrows, int batch, std::vector<uint32_t> &host_out) {
+    const size_t vec_bytes = ((size_t)cols * 4 + 255) & ~(size_t)255;
+    const size_t out_bytes = (size_t)batch * nrows * 4;
+    uint8_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, vec_bytes + out_bytes + 16));
+    host_out.resize((size_t)batch * nrows);
+    hipError_t e = hipMemcpyAsync(tmp, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = gswk::launch_row_dot(ctx->ring, d_x, stride, ld, cols, row0, nrows, (const uint32_t *)tmp, batch,
+                                 (uint32_t *)(tmp + vec_bytes), ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host_out.data(), tmp + vec_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(e);
+    return GSW_OK;
+}
+
+// gsw_impl.rs:127-131
+static uint32_t is_zero_one(const gswk::RingDesc &ring, uint32_t x) {
+    const uint64_t mx = ring.kind == gswk::kRingFp ? (uint64_t)gswk::kFpP - 1 : (uint64_t)ring.mask;
+    const uint32_t lo = (uint32_t)(mx / 4), hi = (uint32_t)(3 * mx / 4);  // both < q: R::from is the identity
+    return (x >= lo && x <= hi) ? 1u : 0u;
+}
+
+int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
+                      uint32_t *h_bits_out, uint32_t *h_raw_out) {
+    if (!ctx || !h_s || !d_cc || !h_bits_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (batch == 0) return GSW_OK;
+    if (int rc = use_device(ctx)) return rc;
+    std::vector<uint32_t> raw;
+    if (int rc = row_dots(ctx, h_s, ctx->width, d_cc, stride, ctx->ld, ctx->ring.ell - 1, 1, batch, raw)) return rc;
+    for (int b = 0; b < batch; ++b) {
+        h_bits_out[b] = is_zero_one(ctx->ring, raw[b]);
+        if (h_raw_out) h_raw_out[b] = raw[b];
+    }
+    return GSW_OK;
+}
+
+int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
+                         uint32_t *h_messages_out) {
+    if (!ctx || !h_s || !d_cc || !h_messages_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (ctx->ring.kind == gswk::kRingFp) return fail(GSW_E_UNSUPPORTED, "Only supported for pow2 rings!");  // gsw_impl.rs:69
+    if (batch == 0) return GSW_OK;
+    if (int rc = use_device(ctx)) return rc;
+    const int ell = ctx->ring.ell;
+    std::vector<uint32_t> dots;
+    if (int rc = row_dots(ctx, h_s, ctx->width, d_cc, stride, ctx->ld, 0, ell, batch, dots)) return rc;
+    for (int b = 0; b < batch; ++b) {
+        // gsw_impl.rs:72-82: peel the message bits from the most significant gadget row down
+        const uint32_t *slice = dots.data() + (size_t)b * ell;
+        uint64_t recovered = 0;
+        for (int i = 0; i < ell; ++i) {
+            const uint32_t entry = slice[ell - 1 - i];
+            const uint32_t recovered_exp = (uint32_t)(recovered << (ell - i - 1)) & ctx->ring.mask;
+            const uint32_t current = (entry - recovered_exp) & ctx->ring.mask;
+            recovered ^= (uint64_t)is_zero_one(ctx->ring, current) << i;
+        }
+        h_messages_out[b] = (uint32_t)recovered & ctx->ring.mask;
+    }
+    return GSW_OK;
+}
+
+int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, const uint32_t *h_vec,
+               uint32_t *d_out) {
+    if (!ctx || !d_mat || !h_vec || !d_out || rows < 0 || cols < 1 || ld < cols) return fail(GSW_E_INVALID, "bad argument");
+    if (rows == 0) return GSW_OK;
+    if (int rc = use_device(ctx)) return rc;
+    uint32_t *d_vec = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_vec, (size_t)cols * 4 + 16));
+    hipError_t e = hipMemcpyAsync(d_vec, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream);
+    // the grid's x dimension carries the rows in slabs of at most 65535
+    for (int r0 = 0; e == hipSuccess && r0 < rows; r0 += 32768) {
+        const int cur = rows - r0 < 32768 ? rows - r0 : 32768;
+        e = gswk::launch_row_dot(ctx->ring, d_mat, 0, ld, cols, r0, cur, d_vec, 1, d_out + r0, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_vec);
+    HIP_TRY(e);
+    return GSW_OK;
+}
+
+int gsw_decrypt_dense(gsw_ctx *ctx, const uint32_t *h_v, const uint32_t *d_c, uint32_t *h_bit_out) {
+    if (!ctx || !h_v || !d_c || !h_bit_out) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    std::vector<uint32_t> raw;
+    if (int rc = row_dots(ctx, h_v, ctx->big_n, d_c, 0, ctx->big_n, ctx->ring.ell - 1, 1, 1, raw)) return rc;
+    *h_bit_out = is_zero_one(ctx->ring, raw[0]);
+    return GSW_OK;
+}
+
+// ---- sampling and digests ----
+
+int gsw_fill_uniform(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint64_t min, uint64_t max, int unchecked,
+                     uint32_t *d_out, size_t count) {
+    if (!ctx || !d_out) return fail(GSW_E_INVALID, "bad argument");
+    if (!unchecked && max > gswk::kFpP) return fail(GSW_E_INVALID, "assertion failed: max <= P");  // error_sampling.rs:21
+    if (min > max || max - min >= (1ull << 32)) return fail(GSW_E_INVALID, "range must fit 32 bits");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_fill_uniform(ctx->ring, seed, stream, min, max, d_out, count, ctx->stream));
+    return GSW_OK;
+}
+
+int gsw_sample_naive(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_out, size_t count) {
+    // error_sampling.rs:75-79: rnd_ring_elm(0, P >> 15) * NOISE_CONST, NOISE_CONST = 1
+    return gsw_fill_uniform(ctx, seed, stream, 0, gswk::kFpP >> 15, 1, d_out, count);
+}
+
+int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sigma, uint32_t *d_out, size_t count) {
+    if (!ctx || !d_out || !(sigma > 0.0) || sigma > 300.0) return fail(GSW_E_INVALID, "bad argument (0 < sigma <= 300)");
+    if (int rc = use_device(ctx)) return rc;
+    std::vector<uint64_t> cum;
+    int kmax = 0;
+    gaussian_table(sigma, cum, kmax);
+    uint64_t *d_cum = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cum, cum.size() * 8));
+    hipError_t e = hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = gswk::launch_sample_table(ctx->ring, seed, stream, d_cum, (int)cum.size(), kmax, d_out, count, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_cum);
+    HIP_TRY(e);
+    return GSW_OK;
+}
+
+int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch, uint64_t *d_digests) {
+    if (!ctx || !d_x || !d_digests || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_digest(d_x, stride, count, batch, (unsigned long long *)d_digests, ctx->stream));
+    return GSW_OK;
+}
+
+}  // extern "C"

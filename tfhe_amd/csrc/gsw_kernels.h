@@ -1,0 +1,92 @@
+// Launch interface between the C-ABI layer (gsw_capi.hip) and the gfx950 kernels
+// (gsw_kernels.hip).  Everything here is device-pointer based and asynchronous on `stream`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gswk {
+
+constexpr int kRingFp = 0;
+constexpr int kRingZpow2 = 1;
+constexpr uint32_t kFpP = 2147483647u;
+
+// Tile geometry of the contraction kernel.
+constexpr int kTileRows = 256;    // output rows per workgroup
+constexpr int kTileCols = 32;     // output columns (each 4 byte limbs wide) per workgroup
+constexpr int kStageElems = 4;    // left-operand elements (32 K-slots each) per pipeline stage
+constexpr int kFragBytes = 1024;  // one 32x32 int8 MFMA operand fragment
+
+struct RingDesc {
+    int kind;       // kRingFp / kRingZpow2
+    int ell;        // bits per element (R::Num_Bits)
+    uint32_t mask;  // p for Fp, 2^M - 1 for Zpow2
+};
+
+// epilogue modes of the contraction
+constexpr int kModeMul = 0;      // out = P
+constexpr int kModeNand = 1;     // out = G - P
+constexpr int kModeEncrypt = 2;  // out = P + addend[b] * G
+
+struct GemmArgs {
+    const uint32_t *lhs;  // binary operand as packed words: M rows x ld_lhs, ell bits used per word
+    size_t lhs_stride;    // uint32 elements between batch entries
+    const uint8_t *rhs;   // prepared limb planes: [NT][E4][4][1024]
+    size_t rhs_stride;    // bytes between batch entries
+    uint32_t *out;        // M rows x ld_out
+    size_t out_stride;
+    const uint32_t *addend;  // kModeEncrypt: one message per batch entry
+    int rows;                // M
+    int e4;                  // left-operand words per row, multiple of kStageElems
+    int ld_lhs;
+    int out_cols;  // valid output columns W
+    int ld_out;
+    int batch;
+    int mode;
+};
+
+inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }
+inline size_t prepared_bytes(int out_cols, int e4) { return (size_t)col_tiles(out_cols) * e4 * 4 * kFragBytes; }
+
+// Right-operand preparation: src is rows_valid x cols_valid (leading dim ld_src); K-slot (e, bit) is
+// source row e*ell + bit.  dst gets [NT][e4][4 limbs][1024 B] signed (value - 128) byte planes.
+struct PrepArgs {
+    const uint32_t *src;
+    size_t src_stride;  // uint32 elements between batch entries
+    uint8_t *dst;
+    size_t dst_stride;  // bytes
+    int rows_valid;
+    int cols_valid;
+    int ld_src;
+    int elems;  // valid K elements (rows_valid = elems * ell)
+    int e4;
+    int batch;
+};
+
+hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream);
+// variant: 0 = LDS-DMA staging (default), 1 = register staging
+hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
+
+hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, uint32_t *out,
+                             hipStream_t stream);
+hipError_t launch_bit_decomp_inv(const RingDesc &ring, const uint32_t *in, int rows, int cols, uint32_t *out,
+                                 int ld_out, int quirk, hipStream_t stream);
+hipError_t launch_add(const RingDesc &ring, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t count,
+                      hipStream_t stream);
+hipError_t launch_mult_const(const RingDesc &ring, uint32_t *x, uint32_t k, size_t count, hipStream_t stream);
+hipError_t launch_mul_dense(const RingDesc &ring, const uint32_t *a, const uint32_t *b, uint32_t *out, int dim,
+                            int nand, hipStream_t stream);
+// out[b * nrows + k] = <x_b[row0 + k, 0..cols), vec> mod q
+hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride, int ld, int cols, int row0,
+                          int nrows, const uint32_t *vec, int batch, uint32_t *out, hipStream_t stream);
+hipError_t launch_fill_uniform(const RingDesc &ring, uint64_t seed, uint64_t stream_id, uint64_t min, uint64_t max,
+                               uint32_t *out, size_t count, hipStream_t stream);
+hipError_t launch_random_words(uint64_t seed, uint64_t stream_id, uint32_t *out, int rows, int words, int ld,
+                               int ell, int last_bits, int batch, size_t stride, hipStream_t stream);
+hipError_t launch_sample_table(const RingDesc &ring, uint64_t seed, uint64_t stream_id, const uint64_t *cum,
+                               int table_len, int kmax, uint32_t *out, size_t count, hipStream_t stream);
+hipError_t launch_digest(const uint32_t *x, size_t stride, size_t count, int batch, unsigned long long *digests,
+                         hipStream_t stream);
+
+}  // namespace gswk

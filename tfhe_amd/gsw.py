@@ -1,0 +1,471 @@
+"""Host-side mirror of the reference's `FheScheme<R>` for `GSW<R, T>` over the C-ABI engine.
+
+Same method names, argument meaning and error behaviour as src/gsw/mod.rs:12-26 and
+src/gsw/gsw_impl.rs:12-125 of n0900/tfhe; the arithmetic runs in the HIP library
+(`libgsw_hip.so`) and nowhere else -- there is no CPU fallback.
+
+Ciphertexts live on the GPU in compact form Cc = BitDecomp^-1_linear(C) (N x (n+1), padded
+leading dimension); `Ciphertext.to_dense()` gives the reference's N x N matrix
+BitDecomp(Cc) (the flattened ciphertext).  The reference's own dense operations on
+arbitrary N x N matrices are the `*_dense` methods.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import FLAG_NAND, GswError, check
+
+FP_P = 2147483647  # src/field.rs:19
+
+
+@dataclass(frozen=True)
+class Ring:
+    """`R: RingElement` (src/lib.rs:15-29): Fp (src/field.rs) or Zpow2<M> (src/pow2_ring.rs)."""
+
+    kind: int
+    log2q: int
+
+    @property
+    def ell(self) -> int:  # R::Num_Bits
+        return 31 if self.kind == _lib.RING_FP_M31 else self.log2q
+
+    @property
+    def q(self) -> int:
+        return FP_P if self.kind == _lib.RING_FP_M31 else 1 << self.log2q
+
+    def max_u64(self) -> int:  # field.rs:36-38, pow2_ring.rs:31-33
+        return self.q - 1
+
+
+def Fp() -> Ring:
+    return Ring(_lib.RING_FP_M31, 31)
+
+
+def Zpow2(m: int) -> Ring:
+    return Ring(_lib.RING_ZPOW2, m)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed block owned by an engine context."""
+
+    def __init__(self, engine: "Engine", nbytes: int):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        ptr = C.c_void_p()
+        check(_lib.lib().gsw_malloc(engine.handle, self.nbytes, C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def free(self):
+        if self.ptr and self.engine.handle:
+            _lib.lib().gsw_free(self.engine.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        check(_lib.lib().gsw_memcpy_h2d(self.engine.handle, self.ptr + offset, arr.ctypes.data, arr.nbytes))
+
+    def download(self, dtype, count: int, offset: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        check(_lib.lib().gsw_memcpy_d2h(self.engine.handle, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+
+class Engine:
+    """One `gsw_ctx`: ring, (n, m), GPU and stream."""
+
+    def __init__(self, ring: Ring, n: int, m: int, device: int = 0):
+        self.ring, self.n, self.m, self.device = ring, int(n), int(m), int(device)
+        self.handle = None
+        handle = C.c_void_p()
+        check(_lib.lib().gsw_ctx_create(C.byref(handle), ring.kind, ring.log2q, self.n, self.m, self.device))
+        self.handle = handle.value
+        L = _lib.lib()
+        self.ell = L.gsw_ctx_ell(self.handle)
+        self.big_n = L.gsw_ctx_big_n(self.handle)
+        self.ld = L.gsw_ctx_ld(self.handle)
+        self.compact_elems = L.gsw_ctx_compact_elems(self.handle)
+        self.prepared_bytes = L.gsw_ctx_prepared_bytes(self.handle)
+        self.rbits_elems = L.gsw_ctx_rbits_elems(self.handle)
+        self.pk_prepared_bytes = L.gsw_ctx_pk_prepared_bytes(self.handle)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().gsw_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(_lib.lib().gsw_sync(self.handle))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        check(_lib.lib().gsw_ctx_set_stream(self.handle, hip_stream))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def alloc_u32(self, count: int) -> DeviceBuffer:
+        return DeviceBuffer(self, 4 * count)
+
+    # ---- timing of the two hot kernels (HIP events on the stream they run on) ----
+    def enable_timing(self, on: bool = True):
+        check(_lib.lib().gsw_ctx_enable_timing(self.handle, int(on)))
+
+    def reset_timing(self):
+        check(_lib.lib().gsw_ctx_reset_timing(self.handle))
+
+    def kernel_time(self, which: int):
+        ms, count = C.c_double(0), C.c_long(0)
+        check(_lib.lib().gsw_ctx_kernel_time(self.handle, which, C.byref(ms), C.byref(count)))
+        return ms.value, count.value
+
+
+class Ciphertext:
+    """`FheScheme::Ciphertext` held on the GPU in compact form (one or a batch of them)."""
+
+    def __init__(self, engine: Engine, batch: int = 1, buf: Optional[DeviceBuffer] = None):
+        self.engine = engine
+        self.batch = int(batch)
+        self.buf = buf if buf is not None else engine.alloc_u32(engine.compact_elems * self.batch)
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.ptr
+
+    @property
+    def stride(self) -> int:
+        return self.engine.compact_elems
+
+    def entry_ptr(self, b: int) -> int:
+        return self.buf.ptr + 4 * self.stride * b
+
+    @classmethod
+    def from_compact(cls, engine: Engine, host) -> "Ciphertext":
+        """Upload N x (n+1) (or batch x N x (n+1)) canonical uint32 values."""
+        host = np.ascontiguousarray(host, dtype=np.uint32)
+        if host.ndim == 2:
+            host = host[None]
+        if host.shape[1:] != (engine.big_n, engine.n + 1):
+            raise ValueError(f"compact ciphertext must be {engine.big_n} x {engine.n + 1}, got {host.shape[1:]}")
+        ct = cls(engine, host.shape[0])
+        for b in range(ct.batch):
+            check(_lib.lib().gsw_upload_compact(engine.handle, ct.entry_ptr(b), host[b].ctypes.data))
+        return ct
+
+    def to_compact(self) -> np.ndarray:
+        e = self.engine
+        out = np.empty((self.batch, e.big_n, e.n + 1), dtype=np.uint32)
+        for b in range(self.batch):
+            check(_lib.lib().gsw_download_compact(e.handle, out[b].ctypes.data, self.entry_ptr(b)))
+        return out[0] if self.batch == 1 else out
+
+    def to_dense(self, b: int = 0) -> np.ndarray:
+        """BitDecomp(Cc): the reference's N x N matrix form (helper.rs:17-21), computed on the GPU."""
+        e = self.engine
+        dense = e.alloc_u32(e.big_n * e.big_n)
+        check(_lib.lib().gsw_bit_decomp(e.handle, self.entry_ptr(b), e.big_n, e.n + 1, e.ld, dense.ptr))
+        return dense.download(np.uint32, e.big_n * e.big_n).reshape(e.big_n, e.big_n)
+
+
+@dataclass
+class SecretKey:
+    """GswSk (src/gsw/sk.rs:13-17): t, s = (1, -t), v = PowersOf2(s)."""
+
+    t: np.ndarray
+    s: np.ndarray
+    v: np.ndarray
+
+
+@dataclass
+class PublicKey:
+    """GswPk (src/gsw/pk.rs:13-16) plus its device-side prepared form."""
+
+    b: np.ndarray
+    pk_matrix: np.ndarray
+    prepared: Optional[DeviceBuffer] = None
+
+
+class GSW:
+    """`GSW<R, T>` (src/gsw/mod.rs:29-38) with `impl FheScheme<R>` (src/gsw/gsw_impl.rs:12-125).
+
+    sampler: "gaussian" (DiscrGaussianSampler::default, sigma = 1), "naive" (NaiveSampler) or a
+    float sigma.  All randomness comes from the engine's seeded counter-based device generator
+    (the reference uses the OS-seeded thread rng; its streams cannot be reproduced).
+    `check_max=False` lifts the reference's `assert!(max <= P)` (error_sampling.rs:21), without
+    which `keygen` over Zpow2<32> cannot run.
+    """
+
+    def __init__(self, ring: Ring, n: int, m: int, sampler="gaussian", seed: int = 0, device: int = 0,
+                 check_max: bool = True):
+        self.ring, self.n, self.m = ring, int(n), int(m)
+        self.sampler, self.seed, self.check_max = sampler, int(seed), check_max
+        self.engine = Engine(ring, n, m, device)
+        self._draw = 0
+
+    # ---- helpers ----
+    def _stream(self) -> int:
+        self._draw += 1
+        return self._draw
+
+    def _uniform(self, lo: int, hi: int, count: int) -> DeviceBuffer:
+        buf = self.engine.alloc_u32(count)
+        check(_lib.lib().gsw_fill_uniform(self.engine.handle, self.seed, self._stream(), lo, hi,
+                                          int(not self.check_max), buf.ptr, count))
+        return buf
+
+    def _errors(self, count: int) -> DeviceBuffer:
+        buf = self.engine.alloc_u32(count)
+        L, h = _lib.lib(), self.engine.handle
+        if self.sampler == "naive":
+            check(L.gsw_sample_naive(h, self.seed, self._stream(), buf.ptr, count))
+        else:
+            sigma = 1.0 if self.sampler == "gaussian" else float(self.sampler)
+            check(L.gsw_sample_gaussian(h, self.seed, self._stream(), sigma, buf.ptr, count))
+        return buf
+
+    def _neg(self, x: np.ndarray) -> np.ndarray:
+        q = self.ring.q
+        return ((q - x.astype(np.uint64)) % q).astype(np.uint32)
+
+    def make_sk(self, t) -> SecretKey:
+        """GswSk::new (src/gsw/sk.rs:20-28).  Key assembly is host logic on n + 1 values."""
+        t = np.ascontiguousarray(t, dtype=np.uint32)
+        q, ell = self.ring.q, self.ring.ell
+        s = np.concatenate([np.array([1 % q], dtype=np.uint32), self._neg(t)])
+        g = np.array([(1 << k) % q for k in range(ell)], dtype=np.uint64)  # gsw/mod.rs:58-62
+        v = ((s.astype(np.uint64)[:, None] * g[None, :]) % q).astype(np.uint32).reshape(-1)  # helper.rs:65-77
+        return SecretKey(t, s, v)
+
+    def make_pk(self, rand_b, e, t) -> PublicKey:
+        """GswPk::new (src/gsw/pk.rs:23-39): b = B t + e on the GPU, pk_matrix = [b | B]."""
+        rand_b = np.ascontiguousarray(rand_b, dtype=np.uint32)
+        e = np.ascontiguousarray(e, dtype=np.uint32)
+        t = np.ascontiguousarray(t, dtype=np.uint32)
+        if rand_b.shape[1] != t.size:
+            raise ValueError(f"Dimension Mismatch ncols {rand_b.shape[1]}, {t.size}")  # pk.rs:24
+        if rand_b.shape[0] != e.size:
+            raise ValueError(f"Dimension Mismatch nrows {rand_b.shape[0]}, {e.size}")  # pk.rs:25
+        m, n = rand_b.shape
+        eng, L = self.engine, _lib.lib()
+        d_b, d_e, d_bt = eng.alloc_u32(m * n), eng.alloc_u32(m), eng.alloc_u32(m)
+        d_b.upload(rand_b)
+        d_e.upload(e)
+        check(L.gsw_matvec(eng.handle, d_b.ptr, m, n, n, t.ctypes.data, d_bt.ptr))
+        check(L.gsw_add(eng.handle, d_bt.ptr, d_e.ptr, d_bt.ptr, m))
+        b = d_bt.download(np.uint32, m)
+        pk_matrix = np.concatenate([b[:, None], rand_b], axis=1)
+        pk = PublicKey(b, pk_matrix)
+        if (m, n) == (self.m, self.n):
+            pk.prepared = eng.alloc(eng.pk_prepared_bytes)
+            check(L.gsw_prepare_pk(eng.handle, np.ascontiguousarray(pk_matrix).ctypes.data, pk.prepared.ptr))
+        return pk
+
+    # ---- FheScheme ----
+    def keygen(self):
+        """src/gsw/gsw_impl.rs:17-25."""
+        mx = self.ring.max_u64()
+        try:
+            t = self._uniform(0, mx, self.n).download(np.uint32, self.n)
+            err = self._errors(self.m).download(np.uint32, self.m)
+            rand_b = self._uniform(0, mx, self.m * self.n).download(np.uint32, self.m * self.n)
+        except GswError as exc:
+            if exc.code == _lib.E_INVALID and "max <= P" in exc.message:
+                raise AssertionError(exc.message) from exc  # the reference panics here (error_sampling.rs:21)
+            raise
+        sk = self.make_sk(t)
+        return sk, self.make_pk(rand_b.reshape(self.m, self.n), err, t)
+
+    def encrypt_batch(self, pk: PublicKey, messages: Sequence[int], rbits=None) -> Ciphertext:
+        """Batched src/gsw/gsw_impl.rs:27-42 in compact form: R * pk_matrix + message * G.
+
+        rbits: optional (batch, N, m) 0/1 bytes standing for rnd_dmatrix(N, m, 0, 1); when absent the
+        seeded device generator draws them.
+        """
+        eng, L = self.engine, _lib.lib()
+        if pk.prepared is None:
+            raise ValueError("public key was built for different (n, m)")
+        msgs = np.ascontiguousarray(messages, dtype=np.uint32)
+        batch = msgs.size
+        d_r = eng.alloc_u32(eng.rbits_elems * batch)
+        if rbits is None:
+            check(L.gsw_random_rbits(eng.handle, self.seed, self._stream(), d_r.ptr, batch))
+        else:
+            rbits = np.ascontiguousarray(rbits, dtype=np.uint8).reshape(batch, eng.big_n, self.m)
+            for b in range(batch):
+                check(L.gsw_pack_rbits(eng.handle, rbits[b].ctypes.data, d_r.ptr + 4 * eng.rbits_elems * b))
+        d_m = eng.alloc_u32(batch)
+        d_m.upload(msgs)
+        ct = Ciphertext(eng, batch)
+        check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, ct.ptr, ct.stride,
+                                  batch))
+        eng.sync()
+        return ct
+
+    def encrypt(self, pk: PublicKey, message: int, rbits=None) -> Ciphertext:
+        """src/gsw/gsw_impl.rs:27-42."""
+        return self.encrypt_batch(pk, [message], None if rbits is None else np.asarray(rbits)[None])
+
+    def decrypt_batch(self, sk: SecretKey, ct: Ciphertext, raw: bool = False):
+        eng = self.engine
+        bits = np.empty(ct.batch, dtype=np.uint32)
+        rawv = np.empty(ct.batch, dtype=np.uint32)
+        s = np.ascontiguousarray(sk.s, dtype=np.uint32)
+        check(_lib.lib().gsw_decrypt_batch(eng.handle, s.ctypes.data, ct.ptr, ct.stride, ct.batch, bits.ctypes.data,
+                                           rawv.ctypes.data))
+        return (bits, rawv) if raw else bits
+
+    def decrypt(self, sk: SecretKey, ct: Ciphertext) -> int:
+        """src/gsw/gsw_impl.rs:48-52."""
+        return int(self.decrypt_batch(sk, ct)[0])
+
+    def mp_decrypt_batch(self, sk: SecretKey, ct: Ciphertext) -> np.ndarray:
+        eng = self.engine
+        out = np.empty(ct.batch, dtype=np.uint32)
+        s = np.ascontiguousarray(sk.s, dtype=np.uint32)
+        try:
+            check(_lib.lib().gsw_mp_decrypt_batch(eng.handle, s.ctypes.data, ct.ptr, ct.stride, ct.batch,
+                                                  out.ctypes.data))
+        except GswError as exc:
+            if exc.code == _lib.E_UNSUPPORTED:
+                raise RuntimeError(exc.message) from exc  # "Only supported for pow2 rings!" (gsw_impl.rs:69)
+            raise
+        return out
+
+    def mp_decrypt(self, sk: SecretKey, ct: Ciphertext) -> int:
+        """src/gsw/gsw_impl.rs:67-84."""
+        return int(self.mp_decrypt_batch(sk, ct)[0])
+
+    def _same_size(self, c1: Ciphertext, c2: Ciphertext):
+        if c1.batch != c2.batch or c1.engine.compact_elems != c2.engine.compact_elems:
+            # the reference asserts equal nrows/ncols (gsw_impl.rs:88-89,105-106)
+            raise ValueError("Cannot add Ciphertexts because they are different sizes")
+
+    def add(self, c1: Ciphertext, c2: Ciphertext) -> Ciphertext:
+        """src/gsw/gsw_impl.rs:87-94 (compact form is linear, so this is the same sum)."""
+        self._same_size(c1, c2)
+        out = Ciphertext(self.engine, c1.batch)
+        check(_lib.lib().gsw_add(self.engine.handle, c1.ptr, c2.ptr, out.ptr, c1.stride * c1.batch))
+        return out
+
+    def mult_const(self, ct: Ciphertext, constant: int) -> None:
+        """src/gsw/gsw_impl.rs:97-101: in place, like the reference."""
+        check(_lib.lib().gsw_mult_const(self.engine.handle, ct.ptr, int(constant), ct.stride * ct.batch))
+
+    def _product(self, c1: Ciphertext, c2: Ciphertext, flags: int) -> Ciphertext:
+        self._same_size(c1, c2)
+        out = Ciphertext(self.engine, c1.batch)
+        check(_lib.lib().gsw_mul_gadget_batch(self.engine.handle, c1.ptr, c1.stride, c2.ptr, c2.stride, out.ptr,
+                                              out.stride, c1.batch, flags))
+        return out
+
+    def mult(self, c1: Ciphertext, c2: Ciphertext) -> Ciphertext:
+        """src/gsw/gsw_impl.rs:104-111 on flattened ciphertexts: Pc = G^-1(C1c) * C2c."""
+        return self._product(c1, c2, 0)
+
+    def nand(self, c1: Ciphertext, c2: Ciphertext) -> Ciphertext:
+        """src/gsw/gsw_impl.rs:114-123: I - C1 * C2, i.e. G - Pc in compact form."""
+        return self._product(c1, c2, FLAG_NAND)
+
+    # ---- the reference's dense operations on arbitrary matrices ----
+    def _dense_binary(self, fn, a, b) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError("Cannot add Ciphertexts because they are different sizes")  # sic: gsw_impl.rs:105
+        eng = self.engine
+        dim = a.shape[0]
+        d_a, d_b, d_o = eng.alloc_u32(a.size), eng.alloc_u32(a.size), eng.alloc_u32(a.size)
+        d_a.upload(a)
+        d_b.upload(b)
+        check(fn(eng.handle, d_a.ptr, d_b.ptr, d_o.ptr, dim))
+        return d_o.download(np.uint32, a.size).reshape(dim, dim)
+
+    def mult_dense(self, c1, c2) -> np.ndarray:
+        """src/gsw/gsw_impl.rs:104-111 (default features): the plain N x N x N product."""
+        return self._dense_binary(_lib.lib().gsw_mul_dense, c1, c2)
+
+    def nand_dense(self, c1, c2) -> np.ndarray:
+        """src/gsw/gsw_impl.rs:114-123."""
+        return self._dense_binary(_lib.lib().gsw_nand_dense, c1, c2)
+
+    def add_dense(self, c1, c2) -> np.ndarray:
+        """src/gsw/gsw_impl.rs:87-94."""
+        a = np.ascontiguousarray(c1, dtype=np.uint32)
+        b = np.ascontiguousarray(c2, dtype=np.uint32)
+        if a.shape != b.shape:
+            raise ValueError("Cannot add Ciphertexts because they are different sizes")
+        eng = self.engine
+        d_a, d_b = eng.alloc_u32(a.size), eng.alloc_u32(a.size)
+        d_a.upload(a)
+        d_b.upload(b)
+        check(_lib.lib().gsw_add(eng.handle, d_a.ptr, d_b.ptr, d_a.ptr, a.size))
+        return d_a.download(np.uint32, a.size).reshape(a.shape)
+
+    def mult_const_dense(self, c, constant: int) -> np.ndarray:
+        """src/gsw/gsw_impl.rs:97-101."""
+        a = np.ascontiguousarray(c, dtype=np.uint32)
+        d_a = self.engine.alloc_u32(a.size)
+        d_a.upload(a)
+        check(_lib.lib().gsw_mult_const(self.engine.handle, d_a.ptr, int(constant), a.size))
+        return d_a.download(np.uint32, a.size).reshape(a.shape)
+
+    def decrypt_dense(self, sk: SecretKey, c) -> int:
+        """src/gsw/gsw_impl.rs:48-52 on the reference's N x N matrix."""
+        a = np.ascontiguousarray(c, dtype=np.uint32)
+        eng = self.engine
+        if a.shape != (eng.big_n, eng.big_n):
+            raise ValueError(f"dense ciphertext must be {eng.big_n} x {eng.big_n}")
+        d_a = eng.alloc_u32(a.size)
+        d_a.upload(a)
+        bit = C.c_uint32(0)
+        v = np.ascontiguousarray(sk.v, dtype=np.uint32)
+        check(_lib.lib().gsw_decrypt_dense(eng.handle, v.ctypes.data, d_a.ptr, C.byref(bit)))
+        return int(bit.value)
+
+    # ---- gadget helpers (src/gsw/helper.rs) on host arrays, computed on the GPU ----
+    def bit_decomp_matrix(self, a) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        rows, cols = a.shape
+        eng = self.engine
+        d_in, d_out = eng.alloc_u32(a.size), eng.alloc_u32(a.size * eng.ell)
+        d_in.upload(a)
+        check(_lib.lib().gsw_bit_decomp(eng.handle, d_in.ptr, rows, cols, cols, d_out.ptr))
+        return d_out.download(np.uint32, a.size * eng.ell).reshape(rows, cols * eng.ell)
+
+    def bit_decomp_inv_matrix(self, a, quirk: bool = True) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        rows, wide = a.shape
+        eng = self.engine
+        if wide % eng.ell:
+            raise ValueError("column count must be a multiple of Num_Bits")
+        cols = wide // eng.ell
+        d_in, d_out = eng.alloc_u32(a.size), eng.alloc_u32(rows * cols)
+        d_in.upload(a)
+        check(_lib.lib().gsw_bit_decomp_inv(eng.handle, d_in.ptr, rows, cols, d_out.ptr, cols, int(quirk)))
+        return d_out.download(np.uint32, rows * cols).reshape(rows, cols)
+
+    def flatten_matrix(self, a) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        rows, wide = a.shape
+        eng = self.engine
+        d = eng.alloc_u32(a.size)
+        d.upload(a)
+        check(_lib.lib().gsw_flatten(eng.handle, d.ptr, rows, wide // eng.ell))
+        return d.download(np.uint32, a.size).reshape(rows, wide)
