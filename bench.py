@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: GSW ciphertext mults/s (whole job) on N MI355X GPUs.
+
+A step is one pass of the hot path over one batch of synthetic input resident in HBM:
+`batch` independent products Pc = G^-1(C1c) * C2c mod q (right-operand preparation + int8-MFMA
+contraction) plus a 64-bit digest of every product.  Default workload: BASELINE.json configs[1],
+batch 1024, n = 256, p = 2^31 - 1, on one GPU.  With N > 1 every rank runs its own batch (weak
+scaling, no collective inside the contraction) and the digests plus one sampled product per rank
+are gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import tfhe_amd  # noqa: E402
+from tfhe_amd import _lib, dist as gdist  # noqa: E402
+
+INT8_DENSE_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 ops/clk x 2.4 GHz (2x the bf16 dense MFMA peak)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (ring, n, default batch)
+    "fp_n256": (lambda: tfhe_amd.Fp(), 256, 1024),      # BASELINE.json configs[1]
+    "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # configs[2] shape, per-GPU slice
+    "z32_n512": (lambda: tfhe_amd.Zpow2(32), 512, 256),  # configs[4] shape
+    "fp_n10": (lambda: tfhe_amd.Fp(), 10, 1024),        # configs[0] shape (plumbing)
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
+    ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
+    return ap.parse_args()
+
+
+def algorithmic_ops(big_n: int, n: int) -> float:
+    """int8 ops of one product: binary left operand, 4 byte limbs of the right one, no padding credit."""
+    return 2.0 * big_n * big_n * (n + 1) * 4
+
+
+def algorithmic_bytes(big_n: int, n: int) -> float:
+    return 3.0 * big_n * (n + 1) * 4
+
+
+def load_traffic(workload: str):
+    """HBM bytes per contraction launch from the committed rocprofv3 PMC passes, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(engine, ring, n, pool_t, lhs_idx, rhs_idx, out_t, seconds: float):
+    """Times the CPU oracle (a port of the reference algorithm; the Rust crate cannot be built here) on a
+    bounded sample of the same workload and checks the GPU's products against it bit for bit."""
+    from oracle import gsw_oracle as O  # the checker / CPU baseline: the only use of the oracle in this file
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    ring_o = O.fp() if ring.kind == _lib.RING_FP_M31 else O.zpow2(ring.log2q)
+    og = O.GSW(ring_o, n, n * ring_o.ell)
+    width = n + 1
+
+    def fetch(t, idx):
+        return np.ascontiguousarray(t[idx].cpu().numpy().view(np.uint32)[:, :, :width])
+
+    # calibrate on one product per thread, then size the sample to about `seconds` of wall time
+    first = min(threads, len(lhs_idx))
+    c1, c2 = fetch(pool_t, lhs_idx[:first]), fetch(pool_t, rhs_idx[:first])
+    t0 = time.perf_counter()
+    got = og.mul_gadget_batch(c1, c2, threads=threads)
+    dt = time.perf_counter() - t0
+    verified = bool(np.array_equal(got, fetch(out_t, list(range(first)))))
+    count, total = first, dt
+    extra = int(min(len(lhs_idx) - first, max(0, (seconds - dt) / max(dt, 1e-6)) * first))
+    extra -= extra % threads if extra >= threads else 0
+    if extra > 0:
+        c1, c2 = fetch(pool_t, lhs_idx[first:first + extra]), fetch(pool_t, rhs_idx[first:first + extra])
+        t0 = time.perf_counter()
+        got = og.mul_gadget_batch(c1, c2, threads=threads)
+        total += time.perf_counter() - t0
+        verified = verified and bool(np.array_equal(got, fetch(out_t, list(range(first, first + extra)))))
+        count += extra
+    # the reference's own algorithm (dense N^3 product, one thread: gsw_impl.rs:107) at its test size
+    small = O.GSW(O.fp(), 10, 310)
+    a = O.fill_uniform(O.fp(), 1, 1, 0, 1, 341 * 341).reshape(341, 341)
+    b = O.fill_uniform(O.fp(), 1, 2, 0, O.FP_P - 1, 341 * 341).reshape(341, 341)
+    t0 = time.perf_counter()
+    small.mult(a, b)
+    dense_s = time.perf_counter() - t0
+    big_n = ring_o.big_n(n)
+    return {
+        "value": count / total, "unit": "mults/s", "cores": threads, "kind": "port",
+        "sample": f"{count} products of the same pool (n={n}, N={big_n}) through the compact-form CPU port, "
+                  f"OpenMP over the batch, {total:.1f} s",
+        "gpu_matches_cpu_bit_exact": verified,
+        "reference_dense_algorithm_mults_per_s_1core_extrapolated": 1.0 / (dense_s * (big_n / 341.0) ** 3),
+    }
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world = gdist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    make_ring, n, default_batch = WORKLOADS[args.workload]
+    ring = make_ring()
+    batch = args.batch or default_batch
+    gsw = tfhe_amd.GSW(ring, n, n * ring.ell, seed=0x6A5C0000 + rank, device=local_rank)
+    eng, L = gsw.engine, _lib.lib()
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+    big_n, ld, ct = eng.big_n, eng.ld, eng.compact_elems
+    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, max(batch * eng.prepared_bytes, eng.prepared_bytes)))
+
+    # resident pool of synthetic compact ciphertexts: i.i.d. uniform in [0, q), padding columns zero
+    pool = args.pool or min(2 * batch, 2048)
+    pool_t = torch.empty((pool, big_n, ld), dtype=torch.int32, device=dev)
+    _lib.check(L.gsw_fill_uniform(eng.handle, 0x6A5C0000 + 1, rank, 0, ring.max_u64(), 1, pool_t.data_ptr(),
+                                  pool * ct))
+    pool_t[:, :, n + 1:] = 0
+    out_t = torch.empty((batch, big_n, ld), dtype=torch.int32, device=dev)
+    digests = torch.zeros(batch, dtype=torch.int64, device=dev)
+    lhs_idx = [(2 * b) % pool for b in range(batch)]
+    rhs_idx = [(2 * b + 1) % pool for b in range(batch)]
+    # entry b multiplies pool items (2b mod pool, 2b+1 mod pool): with pool = 2 * batch that is one
+    # strided call; a smaller pool wraps around in `pool / 2`-sized calls
+    per_call = min(batch, pool // 2)
+
+    def step():
+        for b0 in range(0, batch, per_call):
+            cur = min(per_call, batch - b0)
+            _lib.check(L.gsw_mul_gadget_batch(eng.handle, pool_t.data_ptr(), 2 * ct, pool_t.data_ptr() + 4 * ct,
+                                              2 * ct, out_t.data_ptr() + 4 * ct * b0, ct, cur, 0))
+        _lib.check(L.gsw_digest_batch(eng.handle, out_t.data_ptr(), ct, ct, batch, digests.data_ptr()))
+        if world > 1:
+            # the only exchange step: digests of every product + one sampled product per rank to rank 0
+            gdist.gather_to_root(digests)
+            gdist.gather_to_root(out_t[0])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    gdist.barrier()
+    eng.enable_timing(True)
+    eng.reset_timing()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    gdist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = gdist.max_over_ranks(elapsed, device=dev)
+    gemm_ms, gemm_launches = eng.kernel_time(0)
+    prep_ms, prep_launches = eng.kernel_time(1)
+    eng.enable_timing(False)
+
+    if rank == 0:
+        total_mults = world * batch * args.steps
+        mults_per_launch = batch * args.steps / max(gemm_launches, 1)
+        gemm_avg_s = gemm_ms / 1e3 / max(gemm_launches, 1)
+        achieved_tops = algorithmic_ops(big_n, n) * mults_per_launch / gemm_avg_s / 1e12 if gemm_avg_s > 0 else 0.0
+        result = {
+            "metric": "GSW ciphertext mults/sec (node)", "value": total_mults / elapsed, "unit": "mults/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8 MFMA, int32 accumulate (exact), u32 ring elements",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
+                                   f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
+                       "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}"},
+            "roofline": {
+                "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
+                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload),
+                "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
+                "kernel": "binlimb_gemm_kernel", "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
+                "products_per_launch": mults_per_launch,
+                "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),
+                "algorithmic_bytes_per_product": algorithmic_bytes(big_n, n),
+                "hbm_gbs_algorithmic": algorithmic_bytes(big_n, n) * total_mults / world / elapsed / 1e9,
+                "hbm_peak_gbs": HBM_PEAK_GBS,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(eng, ring, n, pool_t, lhs_idx, rhs_idx, out_t, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    gdist.barrier()
+    gdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()
