@@ -3,7 +3,7 @@
 
 A step is one pass of the hot path over one batch of synthetic input resident in HBM:
 `batch` independent products Pc = G^-1(C1c) * C2c mod q (right-operand preparation + int8-MFMA
-contraction) plus a 64-bit digest of every product.  Default workload: BASELINE.json configs[1],
+contraction, whose epilogue also accumulates a 64-bit digest of every product).  Default workload: BASELINE.json configs[1],
 batch 1024, n = 256, p = 2^31 - 1, on one GPU.  With N > 1 every rank runs its own batch (weak
 scaling, no collective inside the contraction) and the digests plus one sampled product per rank
 are gathered to rank 0 over RCCL inside the timed region.
@@ -31,6 +31,10 @@ from tfhe_amd import _lib, dist as gdist  # noqa: E402
 
 INT8_DENSE_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 ops/clk x 2.4 GHz (2x the bf16 dense MFMA peak)
 HBM_PEAK_GBS = 8000.0
+DEFAULT_VARIANT = 4
+KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined<8 waves>",
+                2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>",
+                4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>"}
 
 WORKLOADS = {
     # name: (ring, n, default batch)
@@ -49,6 +53,7 @@ def parse_args():
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
+    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..5 (default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -133,6 +138,9 @@ def main():
     make_ring, n, default_batch = WORKLOADS[args.workload]
     ring = make_ring()
     batch = args.batch or default_batch
+    if args.variant is not None:
+        os.environ["GSW_GEMM_VARIANT"] = str(args.variant)
+    variant = int(os.environ.get("GSW_GEMM_VARIANT", DEFAULT_VARIANT))
     gsw = tfhe_amd.GSW(ring, n, n * ring.ell, seed=0x6A5C0000 + rank, device=local_rank)
     eng, L = gsw.engine, _lib.lib()
     stream = torch.cuda.current_stream(dev)
@@ -157,9 +165,10 @@ def main():
     def step():
         for b0 in range(0, batch, per_call):
             cur = min(per_call, batch - b0)
-            _lib.check(L.gsw_mul_gadget_batch(eng.handle, pool_t.data_ptr(), 2 * ct, pool_t.data_ptr() + 4 * ct,
-                                              2 * ct, out_t.data_ptr() + 4 * ct * b0, ct, cur, 0))
-        _lib.check(L.gsw_digest_batch(eng.handle, out_t.data_ptr(), ct, ct, batch, digests.data_ptr()))
+            _lib.check(L.gsw_mul_gadget_batch_digest(eng.handle, pool_t.data_ptr(), 2 * ct,
+                                                     pool_t.data_ptr() + 4 * ct, 2 * ct,
+                                                     out_t.data_ptr() + 4 * ct * b0, ct, cur, 0,
+                                                     digests.data_ptr() + 8 * b0))
         if world > 1:
             # the only exchange step: digests of every product + one sampled product per rank to rank 0
             gdist.gather_to_root(digests)
@@ -201,7 +210,8 @@ def main():
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload),
                 "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
-                "kernel": "binlimb_gemm_kernel", "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
+                "kernel": KERNEL_NAMES[variant],
+                "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
                 "products_per_launch": mults_per_launch,
                 "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),
                 "algorithmic_bytes_per_product": algorithmic_bytes(big_n, n),

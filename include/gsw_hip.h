@@ -117,6 +117,11 @@ int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1,
 /* same, preparing the right operands internally in workspace chunks */
 int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
                          uint32_t *d_out, size_t stride_out, int batch, unsigned flags);
+/* same, and d_digests[b] receives the gsw_digest_batch() digest of product b (computed in the
+ * contraction's epilogue, so the products are not read back) */
+int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c,
+                                size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
+                                uint64_t *d_digests);
 
 /* ---- encrypt (gsw_impl.rs:27-42): compact form R * pk + message * G, the same contraction
  *      with the N x m random bit matrix as the binary operand ---- */

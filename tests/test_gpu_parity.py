@@ -46,9 +46,13 @@ def _assert_equal(got, expect, what):
 
 
 # ---------------------------------------------------------------- the hot path, small shapes
-@pytest.mark.parametrize("variant", ["0", "1"])
-@pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 40), ("z30", 10), ("z31", 10),
-                                          ("z32", 10), ("z32", 33), ("z8", 5)])
+# kernel variants: 0 = pipelined 256-row tile (default), 1 = pipelined 512-row tile, 2 = simple LDS-DMA,
+# 3 = simple register staging, 4/5 = pipelined on the 16x16x64 MFMA shape (256/512-row tile).  n + 1 columns: 2, 4, 8 (a packed tile only), 11, 33/34/40 (full + packed
+# tail), 41 (full + unpacked tail), 72 (two full + packed tail of 8)
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5"])
+@pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 7), ("fp", 32), ("fp", 39),
+                                          ("fp", 40), ("fp", 71), ("z30", 10), ("z31", 10), ("z32", 10),
+                                          ("z32", 33), ("z8", 5)])
 def test_mul_gadget_random_operands(oracle, tfhe_amd, ring_name, n, variant):
     """Pc = BitDecomp(C1c) * C2c on uniform random operands (every bit pattern exercised)."""
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
@@ -91,6 +95,17 @@ def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
         _assert_equal(got[b], og.mul_gadget(c1[b], c2), f"broadcast rhs [{b}]")
     raw = out.buf.download(np.uint32, eng.compact_elems * 4).reshape(4, eng.big_n, eng.ld)
     assert eng.ld == 12 and (raw[:, :, n + 1:] == 0).all()
+    # digests from the contraction's epilogue == the digest kernel == the oracle's digest of the buffer
+    dig = eng.alloc(8 * 4)
+    dig2 = eng.alloc(8 * 4)
+    _lib.check(_lib.lib().gsw_mul_gadget_batch_digest(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, out.ptr, out.stride,
+                                                      4, _lib.FLAG_NAND, dig.ptr))
+    _lib.check(_lib.lib().gsw_digest_batch(eng.handle, out.ptr, out.stride, eng.compact_elems, 4, dig2.ptr))
+    raw = out.buf.download(np.uint32, eng.compact_elems * 4).reshape(4, -1)
+    want = [oracle.digest(raw[b]) for b in range(4)]
+    assert dig.download(np.uint64, 4).tolist() == want == dig2.download(np.uint64, 4).tolist()
+    for b in range(4):
+        _assert_equal(out.to_compact()[b], og.mul_gadget(c1[b], c2, flags=oracle.FLAG_NAND), f"nand+digest [{b}]")
     # empty batch is a no-op
     _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, out.ptr, out.stride, 0, 0))
     with pytest.raises(tfhe_amd.GswError):

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
+    "gsw_mul_gadget_batch_digest": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint, _vp]),
     "gsw_prepare_pk": (_i, [_vp, _vp, _vp]),
     "gsw_pack_rbits": (_i, [_vp, _vp, _vp]),
     "gsw_random_rbits": (_i, [_vp, _u64, _u64, _vp, _i]),

@@ -57,6 +57,7 @@ struct gsw_ctx {
     size_t ws_bytes;
     size_t ws_limit;
     int gemm_variant;
+    bool packed_tail;  // the last column tile of prepared operands is stored packed
     bool timing;
     std::vector<TimedLaunch> timed[2];
 };
@@ -188,9 +189,14 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_limit = (size_t)2 << 30;
-    ctx->gemm_variant = 0;
+    ctx->gemm_variant = 4;  // pipelined 16x16x64 kernel, 256-row tile
     ctx->timing = false;
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
+    if (ctx->gemm_variant < 0 || ctx->gemm_variant > 5) {
+        delete ctx;
+        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..5");
+    }
+    ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -234,9 +240,9 @@ int gsw_ctx_ell(const gsw_ctx *ctx) { return ctx ? ctx->ring.ell : 0; }
 int gsw_ctx_big_n(const gsw_ctx *ctx) { return ctx ? ctx->big_n : 0; }
 int gsw_ctx_ld(const gsw_ctx *ctx) { return ctx ? ctx->ld : 0; }
 size_t gsw_ctx_compact_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld : 0; }
-size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld) : 0; }
+size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld, ctx->packed_tail) : 0; }
 size_t gsw_ctx_rbits_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld_r : 0; }
-size_t gsw_ctx_pk_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld_r) : 0; }
+size_t gsw_ctx_pk_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->ld_r, ctx->packed_tail) : 0; }
 
 int gsw_ctx_set_workspace_limit(gsw_ctx *ctx, size_t bytes) {
     if (!ctx) return fail(GSW_E_INVALID, "null context");
@@ -424,12 +430,14 @@ int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void
     a.elems = ctx->width;
     a.e4 = ctx->ld;
     a.batch = batch;
+    a.packed_tail = ctx->packed_tail;
+    a.layout16 = ctx->gemm_variant >= 4;
     return run_prepare(ctx, a);
 }
 
-int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
-                            size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch,
-                            unsigned flags) {
+static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
+                        size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
+                        uint64_t *d_digests) {
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_prepared || !aligned16(d_prepared) || (stride_prepared_bytes & 15u))
@@ -450,15 +458,25 @@ int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1,
     a.ld_out = ctx->ld;
     a.batch = batch;
     a.mode = (flags & GSW_FLAG_NAND) ? gswk::kModeNand : gswk::kModeMul;
+    a.packed_tail = ctx->packed_tail;
+    a.digests = (unsigned long long *)d_digests;
     return run_gemm(ctx, a);
 }
 
-int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
-                         uint32_t *d_out, size_t stride_out, int batch, unsigned flags) {
+int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
+                            size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch,
+                            unsigned flags) {
+    return mul_prepared(ctx, d_c1c, stride1, d_prepared, stride_prepared_bytes, d_out, stride_out, batch, flags,
+                        nullptr);
+}
+
+static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
+                     uint32_t *d_out, size_t stride_out, int batch, unsigned flags, uint64_t *d_digests) {
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
     if (int rc = use_device(ctx)) return rc;
+    if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, sizeof(uint64_t) * (size_t)batch, ctx->stream));
     const size_t prep = gsw_ctx_prepared_bytes(ctx);
     // a shared right operand (stride 0) is prepared once; otherwise work in workspace-sized chunks
     const bool shared = stride2 == 0;
@@ -468,16 +486,28 @@ int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, co
     if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
     if (shared) {
         if (int rc = gsw_prepare_rhs(ctx, d_c2c, 0, ctx->ws, 1)) return rc;
-        return gsw_mul_gadget_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags);
+        return mul_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags, d_digests);
     }
     for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
         const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
         if (int rc = gsw_prepare_rhs(ctx, d_c2c + b0 * stride2, stride2, ctx->ws, cur)) return rc;
-        if (int rc = gsw_mul_gadget_prepared(ctx, d_c1c + b0 * stride1, stride1, ctx->ws, prep,
-                                             d_out + b0 * stride_out, stride_out, cur, flags))
+        if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, ctx->ws, prep, d_out + b0 * stride_out,
+                                  stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr))
             return rc;
     }
     return GSW_OK;
+}
+
+int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
+                         uint32_t *d_out, size_t stride_out, int batch, unsigned flags) {
+    return mul_batch(ctx, d_c1c, stride1, d_c2c, stride2, d_out, stride_out, batch, flags, nullptr);
+}
+
+int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c,
+                                size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
+                                uint64_t *d_digests) {
+    if (!d_digests) return fail(GSW_E_INVALID, "null digest buffer");
+    return mul_batch(ctx, d_c1c, stride1, d_c2c, stride2, d_out, stride_out, batch, flags, d_digests);
 }
 
 // ---- encrypt ----
@@ -506,6 +536,8 @@ int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepare
         a.elems = ctx->words;
         a.e4 = ctx->ld_r;
         a.batch = 1;
+        a.packed_tail = ctx->packed_tail;
+        a.layout16 = ctx->gemm_variant >= 4;
         rc = run_prepare(ctx, a);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -562,6 +594,7 @@ int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d
     a.ld_out = ctx->ld;
     a.batch = batch;
     a.mode = gswk::kModeEncrypt;
+    a.packed_tail = ctx->packed_tail;
     return run_gemm(ctx, a);
 }
 

@@ -44,10 +44,18 @@ struct GemmArgs {
     int ld_out;
     int batch;
     int mode;
+    int packed_tail;              // the last column tile is a packed one (see prepared_bytes)
+    unsigned long long *digests;  // optional: digests[b] += digest of the stored tile (zeroed by the caller)
 };
 
 inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }
-inline size_t prepared_bytes(int out_cols, int e4) { return (size_t)col_tiles(out_cols) * e4 * 4 * kFragBytes; }
+// A last column tile with at most 8 valid columns can be stored packed: one fragment per K element
+// whose MFMA column 8 l + c carries limb l of column c (a quarter of the MFMA work of a full tile).
+inline bool can_pack_tail(int out_cols) { return out_cols % kTileCols >= 1 && out_cols % kTileCols <= 8; }
+inline size_t prepared_bytes(int out_cols, int e4, bool packed_tail) {
+    const size_t frags = (size_t)col_tiles(out_cols) * 4 - (packed_tail ? 3 : 0);
+    return frags * e4 * kFragBytes;
+}
 
 // Right-operand preparation: src is rows_valid x cols_valid (leading dim ld_src); K-slot (e, bit) is
 // source row e*ell + bit.  dst gets [NT][e4][4 limbs][1024 B] signed (value - 128) byte planes.
@@ -62,10 +70,15 @@ struct PrepArgs {
     int elems;  // valid K elements (rows_valid = elems * ell)
     int e4;
     int batch;
+    int packed_tail;
+    int layout16;  // fragment order of the 16x16x64 kernels (variants 4, 5) instead of the 32x32x32 ones
 };
 
 hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream);
-// variant: 0 = LDS-DMA staging (default), 1 = register staging
+// variant: 0 = pipelined 32x32x32 MFMA, 256-row tile; 1 = same, 512-row tile;
+//          2 = simple two-buffer LDS-DMA kernel; 3 = simple kernel with register staging;
+//          4 = pipelined 16x16x64 MFMA, 256-row tile; 5 = same, 512-row tile.
+// The prepared right operand must have been built for the variant's fragment order.
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
 
 hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, uint32_t *out,

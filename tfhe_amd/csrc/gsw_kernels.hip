@@ -14,6 +14,8 @@
 // the left fragment two VALU ops per dword: ((x >> 4h) >> i) & 0x01010101.
 #include "gsw_kernels.h"
 
+#include <type_traits>
+
 namespace gswk {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -78,18 +80,20 @@ __device__ __forceinline__ uint64_t rng_u64(uint64_t seed, uint64_t stream, uint
 //
 // One workgroup per (K element e, column tile nt, batch entry): reads the 32 source rows
 // e*ell .. e*ell+31 x 32 columns (128 B contiguous per row), splits every word into four byte
-// limbs, biases them by -128 (the int8 MFMA is signed) and writes the four 1 KiB fragments
-// through LDS so that the global stores are 16 B per lane and fully coalesced.
-// Thread (cc = tid & 31, h = tid >> 7, i = (tid >> 5) & 3) owns fragment dword i of lane 32h + cc.
+// limbs, biases them by -128 (the int8 MFMA is signed) and writes the 1 KiB fragments through
+// LDS so that the global stores are 16 B per lane and fully coalesced.
+// Full tile: thread (cc = tid & 31, i = (tid >> 5) & 3, h = tid >> 7) owns dword i of lane
+// 32h + cc in each of the four limb fragments.  Packed tail tile (at most 8 valid columns): one
+// fragment whose MFMA column l*8 + cc carries limb l of column cc.
 
 __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[4 * 256];
     const int tid = threadIdx.x;
     const int e = blockIdx.x, nt = blockIdx.y, b = blockIdx.z;
-    const int nt_count = gridDim.y;
-    const int cc = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
+    const int cidx = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
+    const bool packed = a.packed_tail && nt == (int)gridDim.y - 1;
     const uint32_t *src = a.src + (size_t)b * a.src_stride;
-    const int col = nt * kTileCols + cc;
+    const int col = nt * kTileCols + (packed ? (cidx & 7) : cidx);
     uint32_t limb[4] = {0u, 0u, 0u, 0u};
     if (e < a.elems && col < a.cols_valid) {
 #pragma unroll
@@ -103,29 +107,508 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
             }
         }
     }
+    uint8_t *dst = a.dst + (size_t)b * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
+    if (packed) {
+        const int l = cidx >> 3;
+        tile[(32 * h + cidx) * 4 + i] = l == 0 ? limb[0] : l == 1 ? limb[1] : l == 2 ? limb[2] : limb[3];
+        __syncthreads();
+        if (tid < 64) reinterpret_cast<uint4 *>(dst + (size_t)e * kFragBytes)[tid] = reinterpret_cast<const uint4 *>(tile)[tid];
+    } else {
 #pragma unroll
-    for (int l = 0; l < 4; ++l) tile[l * 256 + (32 * h + cc) * 4 + i] = limb[l];
+        for (int l = 0; l < 4; ++l) tile[l * 256 + (32 * h + cidx) * 4 + i] = limb[l];
+        __syncthreads();
+        reinterpret_cast<uint4 *>(dst + (size_t)e * (4 * kFragBytes))[tid] = reinterpret_cast<const uint4 *>(tile)[tid];
+    }
+}
+
+// The same for the 16x16x64 kernels: one workgroup per (stage t, MFMA step p, column tile, batch
+// entry) builds the fragments [limb][column group] of that step from elements 4t + p (K groups 0, 1)
+// and 4t + 2 + p (K groups 2, 3).  Lane 16 g + c of a fragment: column c of the group, K group g.
+__global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell) {
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 256];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x >> 1, step = blockIdx.x & 1, nt = blockIdx.y, b = blockIdx.z;
+    const int cidx = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
+    const bool packed = a.packed_tail && nt == (int)gridDim.y - 1;
+    const uint32_t *src = a.src + (size_t)b * a.src_stride;
+    const int col = nt * kTileCols + (packed ? (cidx & 7) : cidx);
+#pragma unroll
+    for (int gh = 0; gh < 2; ++gh) {
+        const int e = 4 * t + 2 * gh + step;
+        uint32_t limb[4] = {0u, 0u, 0u, 0u};
+        if (e < a.elems && col < a.cols_valid) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int bit = 4 * h + i + 8 * tt;
+                const int row = e * ell + bit;
+                if (bit < ell && row < a.rows_valid) {
+                    const uint32_t x = src[(size_t)row * a.ld_src + col] ^ 0x80808080u;
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) limb[l] |= ((x >> (8 * l)) & 0xFFu) << (8 * tt);
+                }
+            }
+        }
+        const int g = 2 * gh + h;
+        const int cg = cidx >> 4, c16 = cidx & 15;
+        if (packed) {
+            const int l = cidx >> 3;
+            tile[(cg * 64 + g * 16 + c16) * 4 + i] = l == 0 ? limb[0] : l == 1 ? limb[1] : l == 2 ? limb[2] : limb[3];
+        } else {
+#pragma unroll
+            for (int l = 0; l < 4; ++l) tile[((l * 2 + cg) * 64 + g * 16 + c16) * 4 + i] = limb[l];
+        }
+    }
     __syncthreads();
-    uint8_t *dst = a.dst + (size_t)b * a.dst_stride + ((size_t)nt * a.e4 + e) * (4 * kFragBytes);
-    (void)nt_count;
-    reinterpret_cast<uint4 *>(dst)[tid] = reinterpret_cast<const uint4 *>(tile)[tid];
+    uint8_t *dst = a.dst + (size_t)b * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
+    if (packed) {
+        if (tid < 128)
+            reinterpret_cast<uint4 *>(dst + (size_t)blockIdx.x * (2 * kFragBytes))[tid] =
+                reinterpret_cast<const uint4 *>(tile)[tid];
+    } else {
+        uint4 *d = reinterpret_cast<uint4 *>(dst + (size_t)blockIdx.x * (8 * kFragBytes));
+        d[tid] = reinterpret_cast<const uint4 *>(tile)[tid];
+        d[tid + 256] = reinterpret_cast<const uint4 *>(tile)[tid + 256];
+    }
 }
 
 hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream) {
     if (a.batch <= 0) return hipSuccess;
-    dim3 grid((unsigned)a.e4, (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
-    hipLaunchKernelGGL(prepare_rhs_kernel, grid, dim3(256), 0, stream, a, ring.ell);
+    if (a.layout16) {
+        dim3 grid((unsigned)(a.e4 / 2), (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
+        hipLaunchKernelGGL(prepare_rhs16_kernel, grid, dim3(256), 0, stream, a, ring.ell);
+    } else {
+        dim3 grid((unsigned)a.e4, (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
+        hipLaunchKernelGGL(prepare_rhs_kernel, grid, dim3(256), 0, stream, a, ring.ell);
+    }
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ the contraction
 //
-// Workgroup: 256 threads = 4 waves, output tile 256 rows x 32 columns x 4 limbs.
-// Wave w owns rows 64w .. 64w+63 as two 32-row groups; per K element it issues
-// 2 (row groups) x 4 (limbs) MFMA 32x32x32 i8 that share 2 left and 4 right fragments.
-// Pipeline: two LDS buffers; stage t+1 is fetched by LDS-DMA while stage t is computed.
-// LDS image of a stage: 4 KiB of left words (row r of the tile at 16 r: its 4 words) followed by
-// 16 fragments (element s, limb l at (4 s + l) KiB), each read lane-linearly (conflict free).
+// Workgroup: WAVES waves, output tile 64*WAVES rows x 32 columns x 4 limbs.  Wave w owns rows
+// 64w .. 64w+63 as two 32-row groups; per K element it issues 2 (row groups) x NFRAG MFMA
+// 32x32x32 i8 that share 2 left and NFRAG right fragments (NFRAG = 4 limbs; 1 in a packed tail
+// tile, where one fragment carries all four limbs of up to 8 columns).
+// LDS image of a stage (4 K elements): 16 B per tile row (its 4 left words) followed by 4*NFRAG
+// fragments (element s, limb l at (NFRAG s + l) KiB), each read lane-linearly (conflict free).
+
+// Everything the epilogue needs besides the accumulators.
+struct TileCtx {
+    int b, nt, mt, wave, lane;
+    int ell;
+    uint32_t mask;
+};
+
+// Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5).  The limbs were biased by -128, so every limb sum gets 128 * popcount(row)
+// back; lane r of either half holds the popcount of row r of each group.
+template <int RING, int NFRAG>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
+                                              const v16i (&acc)[2][NFRAG], uint32_t pop0, uint32_t pop1) {
+    const int lane = c.lane, half = lane >> 5, c32 = lane & 31;
+    const int col = c.nt * kTileCols + (NFRAG == 4 ? c32 : (c32 & 7));
+    const bool col_owner = NFRAG == 4 ? true : c32 < 8;
+    const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
+    uint32_t *out = p.out + (size_t)c.b * p.out_stride;
+    unsigned long long dig = 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const uint32_t pop = g == 0 ? pop0 : pop1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const uint32_t bias = 128u * (uint32_t)__shfl((int)pop, rr, 64);
+            const int row = c.mt * tile_rows + c.wave * 64 + g * 32 + rr;
+            uint64_t s0, s1, s2, s3;
+            if (NFRAG == 4) {
+                s0 = (uint32_t)acc[g][0][r] + bias;
+                s1 = (uint32_t)acc[g][1 % NFRAG][r] + bias;
+                s2 = (uint32_t)acc[g][2 % NFRAG][r] + bias;
+                s3 = (uint32_t)acc[g][3 % NFRAG][r] + bias;
+            } else {
+                // packed tile: limb l of column cc sits in MFMA column 8 l + cc of the same half
+                const int v = (int)((uint32_t)acc[g][0][r] + bias);
+                const int base = (lane & 32) | (lane & 7);
+                s0 = (uint32_t)__shfl(v, base, 64);
+                s1 = (uint32_t)__shfl(v, base + 8, 64);
+                s2 = (uint32_t)__shfl(v, base + 16, 64);
+                s3 = (uint32_t)__shfl(v, base + 24, 64);
+            }
+            uint32_t val = ring_from_u64<RING>(s0 + (s1 << 8) + (s2 << 16) + (s3 << 24), c.mask);
+            if (col_owner && row < p.rows && col < p.ld_out) {
+                if (col >= p.out_cols) {
+                    val = 0u;  // keep the padding columns of the compact form zero
+                } else if (p.mode == kModeNand) {
+                    val = ring_sub<RING>(gadget_entry<RING>(row, col, c.ell, c.mask), val, c.mask);
+                } else if (p.mode == kModeEncrypt) {
+                    val = ring_add<RING>(val, ring_mul<RING>(addend, gadget_entry<RING>(row, col, c.ell, c.mask), c.mask),
+                                         c.mask);
+                }
+                const size_t idx = (size_t)row * p.ld_out + col;
+                out[idx] = val;
+                dig += ((unsigned long long)val + 1ull) * ((2ull * idx + 1ull) * 0x9E3779B97F4A7C15ull);
+            }
+        }
+    }
+    if (p.digests) {
+        // one atomic per wave; the sum mod 2^64 does not depend on the order of arrival
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)dig, off, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(dig >> 32), off, 64);
+            dig += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) atomicAdd(&p.digests[c.b], dig);
+    }
+}
+
+// One K element: expand the two left fragments from their words and run the MFMAs.
+template <int NFRAG>
+__device__ __forceinline__ void gemm_kstep(uint32_t x0, uint32_t x1, int sh, const unsigned char *frags, int lane,
+                                           v16i (&acc)[2][NFRAG], uint32_t &pop0, uint32_t &pop1) {
+    pop0 += __popc(x0);
+    pop1 += __popc(x1);
+    const uint32_t y0 = x0 >> sh, y1 = x1 >> sh;
+    v4i f0, f1;
+    f0[0] = (int)(y0 & 0x01010101u);
+    f0[1] = (int)((y0 >> 1) & 0x01010101u);
+    f0[2] = (int)((y0 >> 2) & 0x01010101u);
+    f0[3] = (int)((y0 >> 3) & 0x01010101u);
+    f1[0] = (int)(y1 & 0x01010101u);
+    f1[1] = (int)((y1 >> 1) & 0x01010101u);
+    f1[2] = (int)((y1 >> 2) & 0x01010101u);
+    f1[3] = (int)((y1 >> 3) & 0x01010101u);
+#pragma unroll
+    for (int l = 0; l < NFRAG; ++l) {
+        const v4i fb = *reinterpret_cast<const v4i *>(frags + l * kFragBytes + lane * 16);
+        acc[0][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, fb, acc[0][l], 0, 0, 0);
+        acc[1][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1, fb, acc[1][l], 0, 0, 0);
+    }
+}
+
+// Workgroups id and id+8 share an XCD (round-robin dispatch): give each XCD whole (batch entry,
+// column tile) units so that the mt_count row tiles that stream the same right-operand panel run
+// on one L2.  Placement only affects speed, never results.  Returns false for surplus workgroups.
+__device__ __forceinline__ bool map_workgroup(int batch, int nt_count, int mt_count, int &b, int &nt, int &mt) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    mt = local % mt_count;
+    const int unit = (local / mt_count) * 8 + xcd;
+    if (unit >= batch * nt_count) return false;
+    b = unit / nt_count;
+    nt = unit - b * nt_count;
+    return true;
+}
+
+// ---- pipelined kernel: LDS-DMA issued from inline asm so that the loads of the next two stages
+// stay in flight across the per-stage barrier (counted vmcnt, raw s_barrier, three LDS buffers).
+
+__device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_wave_base) {
+    // global_load_lds_dwordx4: lane i's 16 bytes land at M0 + 16 i.  M0 is saved and restored inside
+    // the statement; the compiler does not count this load, the kernel's own s_waitcnt vmcnt does.
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_base)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+constexpr int kPipeBuffers = 3;
+template <int WAVES>
+constexpr int pipe_lds_bytes() { return kPipeBuffers * (WAVES * 1024 + kStageElems * 4 * kFragBytes); }
+
+template <int RING, int WAVES, int NFRAG>
+__device__ __forceinline__ void gemm_pipelined_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
+                                                    unsigned char *smem) {
+    constexpr int kRows = 64 * WAVES;
+    constexpr int kLhs = WAVES * 1024;
+    constexpr int kStage = kLhs + kStageElems * 4 * kFragBytes;  // buffers are sized for NFRAG = 4
+    constexpr int kPieces = kStageElems * NFRAG;                 // 1 KiB pieces of the right operand per stage
+    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
+    constexpr int kLoads = 1 + kRounds;                          // LDS-DMA instructions per wave per stage
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    int row_load = mt * kRows + tid;
+    if (row_load > p.rows - 1) row_load = p.rows - 1;  // clamped rows are computed but never stored
+    const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;
+    const int stages = p.e4 / kStageElems;
+    const bool wave_active = mt * kRows + wave * 64 < p.rows;
+
+    v16i acc[2][NFRAG];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int l = 0; l < NFRAG; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][l][r] = 0;
+    uint32_t pop0 = 0, pop1 = 0;
+    const int r32 = lane & 31;
+    const int sh = (lane >> 5) * 4;
+
+    auto issue = [&](int t, int buf) {
+        const uint32_t base = lds0 + (uint32_t)(buf * kStage);
+        lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
+        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+#pragma unroll
+        for (int j = 0; j < kRounds; ++j) {
+            // when there are fewer pieces than waves the surplus waves re-load a piece (same bytes,
+            // same place), which keeps the per-wave load count uniform for the counted wait
+            const int piece = (j * WAVES + wave) % kPieces;
+            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
+        }
+    };
+
+    issue(0, 0);
+    if (stages > 1) issue(1, 1);
+    // The loop exists twice -- with and without the arithmetic -- so that a wave whose 64 rows lie
+    // beyond the matrix only stages and synchronises; a branch around the MFMAs inside one loop
+    // would make every accumulator a loop-carried merge of two paths.
+    auto main_loop = [&](auto active_tag) {
+        constexpr bool kActive = decltype(active_tag)::value;
+        int buf = 0;
+        for (int t = 0; t < stages; ++t) {
+            // Stage t was issued before stage t+1: once at most kLoads of this wave's loads are
+            // pending, its share of stage t has landed; the barrier extends that to every wave's
+            // share and also tells that all waves are done reading the buffer the next issue
+            // overwrites.
+            if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
+            else wait_vmcnt_then_barrier<0>();
+            if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
+            if constexpr (kActive) {
+                const unsigned char *sa = smem + buf * kStage;
+                const unsigned char *sb = sa + kLhs;
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + r32) * 16);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + 32 + r32) * 16);
+                gemm_kstep<NFRAG>(a0.x, a1.x, sh, sb + 0 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
+                gemm_kstep<NFRAG>(a0.y, a1.y, sh, sb + 1 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
+                gemm_kstep<NFRAG>(a0.z, a1.z, sh, sb + 2 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
+                gemm_kstep<NFRAG>(a0.w, a1.w, sh, sb + 3 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    };
+    if (wave_active) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    if (wave_active) {
+        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+        gemm_epilogue<RING, NFRAG>(p, c, kRows, acc, pop0, pop1);
+    }
+}
+
+template <int RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm_pipelined(GemmArgs p, int ell, uint32_t mask,
+                                                                         int nt_count, int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm_pipelined_body<RING, WAVES, 1>(p, ell, mask, b, nt, mt, smem);
+    else gemm_pipelined_body<RING, WAVES, 4>(p, ell, mask, b, nt, mt, smem);
+}
+
+// ---- the same pipeline on the 16x16x64 MFMA shape.
+//
+// A wave still owns 64 rows x 32 columns x 4 limbs, now as 4 row groups x (2 column groups x 4 limbs)
+// 16x16 accumulators; operand bytes per useful op are the same as with the 32x32 shape, but the chip
+// holds a higher clock on this shape.  One MFMA covers two K elements: lane l of an operand fragment
+// has row/column l & 15 and K group g = l >> 4; g >> 1 picks the element, g & 1 the half h of its
+// word, fragment dword i byte t stands for bit 4h + i + 8t as before.  Within a stage of 4 elements
+// MFMA step p pairs elements p and p + 2, so a lane reads its two words (one per step) as one 8-byte
+// LDS load.  Right-operand fragments of a stage: [step p][limb l][column group cg] (packed tail:
+// [p][cg], MFMA column 8 l + c of the 32 carrying limb l of column c).
+
+template <int RING, bool PACKED>
+__device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
+                                                const v4i (&acc)[4][PACKED ? 2 : 8], const uint32_t (&pop)[4]) {
+    const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
+    const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
+    uint32_t *out = p.out + (size_t)c.b * p.out_stride;
+    unsigned long long dig = 0;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
+            const int rr = 4 * quad + r;
+            // the words of row rr were split between the K groups: lanes rr (elements p) and rr + 32 (p + 2)
+            const uint32_t bias =
+                128u * (uint32_t)(__shfl((int)pop[rg], rr, 64) + __shfl((int)pop[rg], rr + 32, 64));
+            const int row = c.mt * tile_rows + c.wave * 64 + rg * 16 + rr;
+#pragma unroll
+            for (int cg = 0; cg < (PACKED ? 1 : 2); ++cg) {
+                uint64_t s0, s1, s2, s3;
+                int col;
+                bool owner;
+                if (!PACKED) {
+                    s0 = (uint32_t)acc[rg][(0 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
+                    s1 = (uint32_t)acc[rg][(1 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
+                    s2 = (uint32_t)acc[rg][(2 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
+                    s3 = (uint32_t)acc[rg][(3 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
+                    col = c.nt * kTileCols + cg * 16 + c16;
+                    owner = true;
+                } else {
+                    const int v0 = (int)((uint32_t)acc[rg][0][r] + bias), v1 = (int)((uint32_t)acc[rg][1][r] + bias);
+                    const int base = (lane & 48) | (lane & 7);
+                    s0 = (uint32_t)__shfl(v0, base, 64);
+                    s1 = (uint32_t)__shfl(v0, base + 8, 64);
+                    s2 = (uint32_t)__shfl(v1, base, 64);
+                    s3 = (uint32_t)__shfl(v1, base + 8, 64);
+                    col = c.nt * kTileCols + (c16 & 7);
+                    owner = c16 < 8;
+                }
+                uint32_t val = ring_from_u64<RING>(s0 + (s1 << 8) + (s2 << 16) + (s3 << 24), c.mask);
+                if (owner && row < p.rows && col < p.ld_out) {
+                    if (col >= p.out_cols) {
+                        val = 0u;  // keep the padding columns of the compact form zero
+                    } else if (p.mode == kModeNand) {
+                        val = ring_sub<RING>(gadget_entry<RING>(row, col, c.ell, c.mask), val, c.mask);
+                    } else if (p.mode == kModeEncrypt) {
+                        val = ring_add<RING>(
+                            val, ring_mul<RING>(addend, gadget_entry<RING>(row, col, c.ell, c.mask), c.mask), c.mask);
+                    }
+                    const size_t idx = (size_t)row * p.ld_out + col;
+                    out[idx] = val;
+                    dig += ((unsigned long long)val + 1ull) * ((2ull * idx + 1ull) * 0x9E3779B97F4A7C15ull);
+                }
+            }
+        }
+    }
+    if (p.digests) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)dig, off, 64);
+            const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(dig >> 32), off, 64);
+            dig += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) atomicAdd(&p.digests[c.b], dig);
+    }
+}
+
+template <int RING, int WAVES, bool PACKED>
+__device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
+                                                      int mt, unsigned char *smem) {
+    constexpr int kRows = 64 * WAVES;
+    constexpr int kLhs = WAVES * 1024;
+    constexpr int kStage = kLhs + kStageElems * 4 * kFragBytes;
+    constexpr int kNB = PACKED ? 2 : 8;                 // right fragments per MFMA step
+    constexpr int kPieces = 2 * kNB;                    // per stage: 2 steps
+    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
+    constexpr int kLoads = 1 + kRounds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    int row_load = mt * kRows + tid;
+    if (row_load > p.rows - 1) row_load = p.rows - 1;
+    const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;
+    const int stages = p.e4 / kStageElems;
+    const bool wave_active = mt * kRows + wave * 64 < p.rows;
+
+    v4i acc[4][kNB];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int f = 0; f < kNB; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
+    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    const int r16 = lane & 15;
+    const int sh = ((lane >> 4) & 1) * 4;
+    const int word_pair = (lane >> 5) * 8;  // byte offset of this lane's two words in its row's 16 bytes
+
+    auto issue = [&](int t, int buf) {
+        const uint32_t base = lds0 + (uint32_t)(buf * kStage);
+        lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
+        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+#pragma unroll
+        for (int j = 0; j < kRounds; ++j) {
+            const int piece = (j * WAVES + wave) % kPieces;
+            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
+        }
+    };
+
+    issue(0, 0);
+    if (stages > 1) issue(1, 1);
+    auto main_loop = [&](auto active_tag) {
+        constexpr bool kActive = decltype(active_tag)::value;
+        int buf = 0;
+        for (int t = 0; t < stages; ++t) {
+            if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
+            else wait_vmcnt_then_barrier<0>();
+            if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
+            if constexpr (kActive) {
+                const unsigned char *sa = smem + buf * kStage + wave * 1024 + r16 * 16 + word_pair;
+                const unsigned char *sb = smem + buf * kStage + kLhs + lane * 16;
+                uint2 w[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    w[rg] = *reinterpret_cast<const uint2 *>(sa + rg * 256);
+                    pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
+                }
+#pragma unroll
+                for (int step = 0; step < 2; ++step) {
+                    v4i fa[4];
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
+                        fa[rg][0] = (int)(y & 0x01010101u);
+                        fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+                        fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+                        fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+                    }
+#pragma unroll
+                    for (int f = 0; f < kNB; ++f) {
+                        const v4i fb = *reinterpret_cast<const v4i *>(sb + (step * kNB + f) * kFragBytes);
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+                            acc[rg][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb, acc[rg][f], 0, 0, 0);
+                    }
+                }
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    };
+    if (wave_active) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    if (wave_active) {
+        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
+    }
+}
+
+template <int RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmArgs p, int ell, uint32_t mask,
+                                                                           int nt_count, int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
+    else gemm16_pipelined_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
+}
+
+// ---- simple kernel: two LDS buffers, compiler-managed waits (LDS-DMA builtin or register staging).
+// Kept as the straightforward form of the same contraction, for A/B timing and as a cross-check.
 
 constexpr int kStageLhsBytes = kTileRows * 16;
 constexpr int kStageRhsBytes = kStageElems * 4 * kFragBytes;
@@ -150,16 +633,8 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // Workgroups id and id+8 share an XCD (round-robin dispatch): give each XCD whole
-    // (batch entry, column tile) units so that the mt_count row tiles that stream the same
-    // right-operand panel run on one L2.  Placement only affects speed, never results.
-    const int id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3;
-    const int mt = local % mt_count;
-    const int unit = (local / mt_count) * 8 + xcd;
-    if (unit >= p.batch * nt_count) return;
-    const int b = unit / nt_count, nt = unit - b * nt_count;
+    int b, nt, mt;
+    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
 
     const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
     const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
@@ -198,80 +673,56 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
         const unsigned char *sb = sa + kStageLhsBytes;
         const uint4 a0 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + r32) * 16);
         const uint4 a1 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + 32 + r32) * 16);
-        const uint32_t w0[4] = {a0.x, a0.y, a0.z, a0.w};
-        const uint32_t w1[4] = {a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int s = 0; s < kStageElems; ++s) {
-            pop0 += __popc(w0[s]);
-            pop1 += __popc(w1[s]);
-            const uint32_t y0 = w0[s] >> sh, y1 = w1[s] >> sh;
-            v4i f0, f1;
-            f0[0] = (int)(y0 & 0x01010101u);
-            f0[1] = (int)((y0 >> 1) & 0x01010101u);
-            f0[2] = (int)((y0 >> 2) & 0x01010101u);
-            f0[3] = (int)((y0 >> 3) & 0x01010101u);
-            f1[0] = (int)(y1 & 0x01010101u);
-            f1[1] = (int)((y1 >> 1) & 0x01010101u);
-            f1[2] = (int)((y1 >> 2) & 0x01010101u);
-            f1[3] = (int)((y1 >> 3) & 0x01010101u);
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                const v4i fb = *reinterpret_cast<const v4i *>(sb + (s * 4 + l) * kFragBytes + lane * 16);
-                acc[0][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, fb, acc[0][l], 0, 0, 0);
-                acc[1][l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1, fb, acc[1][l], 0, 0, 0);
-            }
-        }
+        gemm_kstep<4>(a0.x, a1.x, sh, sb + 0 * 4 * kFragBytes, lane, acc, pop0, pop1);
+        gemm_kstep<4>(a0.y, a1.y, sh, sb + 1 * 4 * kFragBytes, lane, acc, pop0, pop1);
+        gemm_kstep<4>(a0.z, a1.z, sh, sb + 2 * 4 * kFragBytes, lane, acc, pop0, pop1);
+        gemm_kstep<4>(a0.w, a1.w, sh, sb + 3 * 4 * kFragBytes, lane, acc, pop0, pop1);
         __syncthreads();
     }
-
-    // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
-    // + 4 (lane >> 5).  The limbs were biased by -128, so every limb sum gets 128 * popcount(row)
-    // back; lane r32 of either half holds the popcount of row r32 of each group.
-    const int col = nt * kTileCols + r32;
-    const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[b] : 0u;
-    uint32_t *out = p.out + (size_t)b * p.out_stride;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const uint32_t pop = g == 0 ? pop0 : pop1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const uint32_t bias = 128u * (uint32_t)__shfl((int)pop, rr, 64);
-            const int row = mt * kTileRows + wave * 64 + g * 32 + rr;
-            const uint64_t s0 = (uint32_t)acc[g][0][r] + bias, s1 = (uint32_t)acc[g][1][r] + bias;
-            const uint64_t s2 = (uint32_t)acc[g][2][r] + bias, s3 = (uint32_t)acc[g][3][r] + bias;
-            uint32_t val = ring_from_u64<RING>(s0 + (s1 << 8) + (s2 << 16) + (s3 << 24), mask);
-            if (row < p.rows && col < p.ld_out) {
-                if (col >= p.out_cols) {
-                    val = 0u;  // keep the padding columns of the compact form zero
-                } else if (p.mode == kModeNand) {
-                    val = ring_sub<RING>(gadget_entry<RING>(row, col, ell, mask), val, mask);
-                } else if (p.mode == kModeEncrypt) {
-                    val = ring_add<RING>(val, ring_mul<RING>(addend, gadget_entry<RING>(row, col, ell, mask), mask),
-                                         mask);
-                }
-                out[(size_t)row * p.ld_out + col] = val;
-            }
-        }
-    }
+    const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+    gemm_epilogue<RING, 4>(p, c, kTileRows, acc, pop0, pop1);
 }
 
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream) {
     if (a.batch <= 0) return hipSuccess;
+    if (variant < 0 || variant > 5) return hipErrorInvalidValue;
+    if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
+    const int tile_rows = (variant == 1 || variant == 5) ? 512 : 256;
     const int nt = col_tiles(a.out_cols);
-    const int mt = (a.rows + kTileRows - 1) / kTileRows;
+    const int mt = (a.rows + tile_rows - 1) / tile_rows;
     const long units = (long)a.batch * nt;
     const long groups = (units + 7) / 8;
     const long blocks = groups * 8 * mt;
     if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)blocks), block(256);
-#define GSW_LAUNCH(RING, DMA)                                                                                   \
-    hipLaunchKernelGGL((binlimb_gemm_kernel<RING, DMA>), grid, block, kGemmLds, stream, a, ring.ell, ring.mask, \
-                       nt, mt)
-    if (ring.kind == kRingFp) {
-        if (variant == 0) GSW_LAUNCH(kRingFp, true); else GSW_LAUNCH(kRingFp, false);
-    } else {
-        if (variant == 0) GSW_LAUNCH(kRingZpow2, true); else GSW_LAUNCH(kRingZpow2, false);
+    dim3 grid((unsigned)blocks);
+    const bool fp = ring.kind == kRingFp;
+#define GSW_LAUNCH(KERNEL, THREADS, LDS) \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), LDS, stream, a, ring.ell, ring.mask, nt, mt)
+    switch (variant) {
+        case 0:
+            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
+            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 4>), 256, pipe_lds_bytes<4>());
+            break;
+        case 1:
+            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 8>), 512, pipe_lds_bytes<8>());
+            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 8>), 512, pipe_lds_bytes<8>());
+            break;
+        case 2:
+            if (fp) GSW_LAUNCH((binlimb_gemm_kernel<kRingFp, true>), 256, kGemmLds);
+            else GSW_LAUNCH((binlimb_gemm_kernel<kRingZpow2, true>), 256, kGemmLds);
+            break;
+        case 3:
+            if (fp) GSW_LAUNCH((binlimb_gemm_kernel<kRingFp, false>), 256, kGemmLds);
+            else GSW_LAUNCH((binlimb_gemm_kernel<kRingZpow2, false>), 256, kGemmLds);
+            break;
+        case 4:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
+            else GSW_LAUNCH((binlimb_gemm16_pipelined<kRingZpow2, 4>), 256, pipe_lds_bytes<4>());
+            break;
+        default:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_pipelined<kRingFp, 8>), 512, pipe_lds_bytes<8>());
+            else GSW_LAUNCH((binlimb_gemm16_pipelined<kRingZpow2, 8>), 512, pipe_lds_bytes<8>());
+            break;
     }
 #undef GSW_LAUNCH
     return hipGetLastError();
