@@ -31,10 +31,11 @@ from tfhe_amd import _lib, dist as gdist  # noqa: E402
 
 INT8_DENSE_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 ops/clk x 2.4 GHz (2x the bf16 dense MFMA peak)
 HBM_PEAK_GBS = 8000.0
-DEFAULT_VARIANT = 4
+DEFAULT_VARIANT = 6
 KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined<8 waves>",
                 2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>",
-                4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>"}
+                4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>",
+                6: "binlimb_gemm16_rowblock<4 waves>", 7: "binlimb_gemm16_rowblock<8 waves>"}
 
 WORKLOADS = {
     # name: (ring, n, default batch)
@@ -53,7 +54,7 @@ def parse_args():
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
-    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..5 (default 4)")
+    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..5 (default 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -210,7 +211,7 @@ def main():
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload),
                 "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
-                "kernel": KERNEL_NAMES[variant],
+                "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} (wrong results by design)"),
                 "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
                 "products_per_launch": mults_per_launch,
                 "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),

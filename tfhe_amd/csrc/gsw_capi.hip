@@ -189,12 +189,12 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_limit = (size_t)2 << 30;
-    ctx->gemm_variant = 4;  // pipelined 16x16x64 kernel, 256-row tile
+    ctx->gemm_variant = 6;  // 16x16x64 MFMA, 256-row tile, 64-byte left-operand loads
     ctx->timing = false;
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
-    if (ctx->gemm_variant < 0 || ctx->gemm_variant > 5) {
+    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 7) && !(ctx->gemm_variant >= 10 && ctx->gemm_variant < 138)) {
         delete ctx;
-        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..5");
+        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..7");
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);

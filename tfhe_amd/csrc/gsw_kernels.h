@@ -77,7 +77,8 @@ struct PrepArgs {
 hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream);
 // variant: 0 = pipelined 32x32x32 MFMA, 256-row tile; 1 = same, 512-row tile;
 //          2 = simple two-buffer LDS-DMA kernel; 3 = simple kernel with register staging;
-//          4 = pipelined 16x16x64 MFMA, 256-row tile; 5 = same, 512-row tile.
+//          4 = pipelined 16x16x64 MFMA, 256-row tile; 5 = same, 512-row tile;
+//          6 = 16x16x64 with 64-byte left-operand loads, 256-row tile; 7 = same, 512-row tile.
 // The prepared right operand must have been built for the variant's fragment order.
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
 

@@ -300,6 +300,35 @@ __device__ __forceinline__ bool map_workgroup(int batch, int nt_count, int mt_co
     return true;
 }
 
+// Blocked placement for the 16x16x64 kernels: one batch entry per XCD at a time, its tiles ordered in
+// passes of kPassRows row tiles x kPassCols column tiles.  The 64 workgroups an XCD runs at a time
+// (32 CUs x 2) are then 16 row tiles that share every right-operand panel among them and 4 column
+// tiles that share every left-operand panel, so each byte crosses the fabric into that L2 about
+// once per pass instead of once per workgroup.  Speed only: results do not depend on placement.
+constexpr int kPassRows = 16, kPassCols = 4;
+__device__ __forceinline__ bool map_workgroup_blocked(int batch, int nt_count, int mt_count, int &b, int &nt,
+                                                      int &mt) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int per = mt_count * nt_count;
+    b = (local / per) * 8 + xcd;
+    if (b >= batch) return false;
+    int w = local % per;
+    for (int m0 = 0; m0 < mt_count; m0 += kPassRows) {
+        const int mc = min(kPassRows, mt_count - m0);
+        for (int n0 = 0; n0 < nt_count; n0 += kPassCols) {
+            const int cnt = mc * min(kPassCols, nt_count - n0);
+            if (w < cnt) {
+                nt = n0 + w / mc;
+                mt = m0 + w % mc;
+                return true;
+            }
+            w -= cnt;
+        }
+    }
+    return false;
+}
+
 // ---- pipelined kernel: LDS-DMA issued from inline asm so that the loads of the next two stages
 // stay in flight across the per-stage barrier (counted vmcnt, raw s_barrier, three LDS buffers).
 
@@ -500,7 +529,11 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
     }
 }
 
-template <int RING, int WAVES, bool PACKED>
+// ABL is a diagnostic switch (timing-only builds with WRONG results): bit 0 drops the waits and
+// barriers, bit 1 the LDS-DMA issue, bit 2 the left-fragment expansion, bit 3 the right-fragment reads,
+// bit 4 makes every workgroup stage the same (first) tile so that all loads hit in L2, bit 5 drops
+// only the left-operand loads, bit 6 only the right-operand loads.
+template <int RING, int WAVES, bool PACKED, int ABL = 0>
 __device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
                                                       int mt, unsigned char *smem) {
     constexpr int kRows = 64 * WAVES;
@@ -516,9 +549,10 @@ __device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
-    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
-    int row_load = mt * kRows + tid;
+    const uint32_t *lhs = p.lhs + (size_t)((ABL & 16) ? 0 : b) * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)((ABL & 16) ? 0 : b) * p.rhs_stride +
+                         (size_t)((ABL & 16) ? 0 : nt) * p.e4 * (4 * kFragBytes);
+    int row_load = ((ABL & 16) ? 0 : mt) * kRows + tid;
     if (row_load > p.rows - 1) row_load = p.rows - 1;
     const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;
     const int stages = p.e4 / kStageElems;
@@ -538,13 +572,16 @@ __device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell
 
     auto issue = [&](int t, int buf) {
         const uint32_t base = lds0 + (uint32_t)(buf * kStage);
-        lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
+        if constexpr (!(ABL & 32))
+            lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
         const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+        if constexpr (!(ABL & 64)) {
 #pragma unroll
-        for (int j = 0; j < kRounds; ++j) {
-            const int piece = (j * WAVES + wave) % kPieces;
-            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
+            for (int j = 0; j < kRounds; ++j) {
+                const int piece = (j * WAVES + wave) % kPieces;
+                lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                          __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
+            }
         }
     };
 
@@ -554,9 +591,13 @@ __device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell
         constexpr bool kActive = decltype(active_tag)::value;
         int buf = 0;
         for (int t = 0; t < stages; ++t) {
-            if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
-            else wait_vmcnt_then_barrier<0>();
-            if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
+            if constexpr (!(ABL & 1)) {
+                if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
+                else wait_vmcnt_then_barrier<0>();
+            }
+            if constexpr (!(ABL & 2)) {
+                if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
+            }
             if constexpr (kActive) {
                 const unsigned char *sa = smem + buf * kStage + wave * 1024 + r16 * 16 + word_pair;
                 const unsigned char *sb = smem + buf * kStage + kLhs + lane * 16;
@@ -566,23 +607,54 @@ __device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell
                     w[rg] = *reinterpret_cast<const uint2 *>(sa + rg * 256);
                     pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
                 }
+                // The right fragments are fetched one group ahead of the MFMAs that use them (two
+                // register sets), so that a wave's LDS latency hides behind its own matrix work.
+                constexpr int kGroup = PACKED ? 2 : 4;            // fragments per group
+                constexpr int kGroups = 2 * kNB / kGroup;         // per stage; fragment index = step * kNB + f
+                v4i fb[2][kGroup];
+                v4i fa[4];
 #pragma unroll
-                for (int step = 0; step < 2; ++step) {
-                    v4i fa[4];
+                for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
-                        fa[rg][0] = (int)(y & 0x01010101u);
-                        fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-                        fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-                        fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+                for (int grp = 0; grp < kGroups; ++grp) {
+                    const int cur = grp & 1;
+                    if (grp + 1 < kGroups) {
+#pragma unroll
+                        for (int j = 0; j < kGroup; ++j) {
+                            if constexpr (ABL & 8) fb[cur ^ 1][j] = fb[cur][j];
+                            else
+                                fb[cur ^ 1][j] =
+                                    *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
+                        }
+                    }
+                    // keep the prefetch above this group's MFMAs (the scheduler would otherwise sink
+                    // every load next to its first use to save registers)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int step = grp * kGroup / kNB;
+                    const int f0 = grp * kGroup - step * kNB;
+                    if (f0 == 0) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
+                            if constexpr (ABL & 4) {
+                                fa[rg][0] = (int)w[rg].x;
+                                fa[rg][1] = (int)w[rg].y;
+                                fa[rg][2] = (int)w[rg].x;
+                                fa[rg][3] = (int)w[rg].y;
+                            } else {
+                                fa[rg][0] = (int)(y & 0x01010101u);
+                                fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+                                fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+                                fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+                            }
+                        }
                     }
 #pragma unroll
-                    for (int f = 0; f < kNB; ++f) {
-                        const v4i fb = *reinterpret_cast<const v4i *>(sb + (step * kNB + f) * kFragBytes);
+                    for (int j = 0; j < kGroup; ++j) {
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg)
-                            acc[rg][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb, acc[rg][f], 0, 0, 0);
+                            acc[rg][f0 + j] =
+                                __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[cur][j], acc[rg][f0 + j], 0, 0, 0);
                     }
                 }
             }
@@ -602,9 +674,186 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmAr
                                                                            int nt_count, int mt_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int b, nt, mt;
-    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, b, nt, mt)) return;
     if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
     else gemm16_pipelined_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
+}
+
+// ---- 16x16x64 pipeline with 64-byte left-operand loads.
+//
+// A 16-byte-per-row load of the left operand touches 64 different cache lines per wave instruction,
+// and those requests, not their bytes, dominate the cost of staging.  Here a wave fetches its own
+// 64 rows in pieces of 16 rows x 64 bytes (the words of four stages at once: 16 requests per
+// instruction), every fourth stage, into a private two-deep LDS ring.  Lane 4r + j of a piece loads
+// the 16 bytes of stage j ^ ((r >> 2) & 3) of row r, so that in the lane-linear LDS image row r keeps
+// stage s at 64 r + 16 (s ^ ((r >> 2) & 3)): the 8-byte reads of one stage by 16 rows then fall on 16
+// different 16-byte slots of the 256-byte bank row (conflict free).  The right operand keeps the
+// three-buffer ring; loads past the last stage are clamped re-loads so that the counted waits stay
+// static (they land in buffers nobody reads again and are drained before the workgroup ends).
+
+template <int WAVES>
+constexpr int rowblock_lds_bytes() { return 2 * WAVES * 4096 + kPipeBuffers * kStageElems * 4 * kFragBytes; }
+
+template <int RING, int WAVES, bool PACKED>
+__device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
+                                                     int mt, unsigned char *smem) {
+    constexpr int kRows = 64 * WAVES;
+    constexpr int kLhsRing = 2 * WAVES * 4096;          // two super-stages of 64 B per row
+    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
+    constexpr int kNB = PACKED ? 2 : 8;
+    constexpr int kPieces = 2 * kNB;
+    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const int stages = p.e4 / kStageElems;
+    const bool wave_active = mt * kRows + wave * 64 < p.rows;
+
+    // left-operand piece rg: lane 4r + j -> row 16 rg + r of this wave, stage slot j
+    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
+    const uint32_t *a_row[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
+        if (row > p.rows - 1) row = p.rows - 1;  // clamped rows are computed but never stored
+        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
+    }
+
+    v4i acc[4][kNB];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int f = 0; f < kNB; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
+    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    const int r16 = lane & 15;
+    const int sh = ((lane >> 4) & 1) * 4;
+    const int swz = (r16 >> 2) & 3;
+    const int word_pair = (lane >> 5) * 8;
+
+    auto issue_lhs = [&](int super_stage) {
+        int st = super_stage * 4 + ld_j;
+        if (st > stages - 1) st = stages - 1;  // past the end: re-load the last stage (never read)
+        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
+    };
+    auto issue_rhs = [&](int t, int buf) {
+        if (t > stages - 1) t = stages - 1;
+        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
+        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+#pragma unroll
+        for (int j = 0; j < kRounds; ++j) {
+            const int piece = (j * WAVES + wave) % kPieces;
+            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+        }
+    };
+
+    issue_lhs(0);
+    issue_rhs(0, 0);
+    issue_rhs(1, 1);
+    int buf = 0;
+    auto stage_body = [&](auto slot_tag, auto active_tag, int t) {
+        constexpr int kSlot = decltype(slot_tag)::value;      // t mod 4
+        constexpr bool kActive = decltype(active_tag)::value;
+        // The previous iteration issued kRounds right-operand loads, plus 4 left-operand loads when it
+        // opened a super-stage; everything older has landed once only those are pending.
+        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
+        if (kSlot == 0) issue_lhs((t >> 2) + 1);
+        issue_rhs(t + 2, buf == 0 ? 2 : buf - 1);
+        if constexpr (kActive) {
+            const unsigned char *sa = smem + ((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
+                                      ((kSlot ^ swz) * 16) + word_pair;
+            const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16;
+            uint2 w[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                w[rg] = *reinterpret_cast<const uint2 *>(sa + rg * 1024);
+                pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
+            }
+            constexpr int kGroup = PACKED ? 2 : 4;
+            constexpr int kGroups = 2 * kNB / kGroup;
+            v4i fb[2][kGroup];
+            v4i fa[4];
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
+#pragma unroll
+            for (int grp = 0; grp < kGroups; ++grp) {
+                const int cur = grp & 1;
+                if (grp + 1 < kGroups) {
+#pragma unroll
+                    for (int j = 0; j < kGroup; ++j)
+                        fb[cur ^ 1][j] = *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this group's MFMAs
+                const int step = grp * kGroup / kNB;
+                const int f0 = grp * kGroup - step * kNB;
+                if (f0 == 0) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
+                        fa[rg][0] = (int)(y & 0x01010101u);
+                        fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+                        fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+                        fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        acc[rg][f0 + j] =
+                            __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[cur][j], acc[rg][f0 + j], 0, 0, 0);
+                }
+            }
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    };
+    auto main_loop = [&](auto active_tag) {
+        for (int t0 = 0; t0 < stages; t0 += 4) {
+            stage_body(std::integral_constant<int, 0>{}, active_tag, t0);
+            if (t0 + 1 < stages) stage_body(std::integral_constant<int, 1>{}, active_tag, t0 + 1);
+            if (t0 + 2 < stages) stage_body(std::integral_constant<int, 2>{}, active_tag, t0 + 2);
+            if (t0 + 3 < stages) stage_body(std::integral_constant<int, 3>{}, active_tag, t0 + 3);
+        }
+    };
+    if (wave_active) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    // the clamped re-loads issued by the last iterations must land before this workgroup's LDS is reused
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave_active) {
+        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
+    }
+}
+
+template <int RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_rowblock(GemmArgs p, int ell, uint32_t mask,
+                                                                          int nt_count, int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
+    else gemm16_rowblock_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
+}
+
+// Timing-only diagnostic builds of the kernel above (Fp, 4 waves): results are wrong by design.
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void binlimb_gemm16_ablate(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                                 int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<kRingFp, 4, true, ABL>(p, ell, mask, b, nt, mt, smem);
+    else gemm16_pipelined_body<kRingFp, 4, false, ABL>(p, ell, mask, b, nt, mt, smem);
 }
 
 // ---- simple kernel: two LDS buffers, compiler-managed waits (LDS-DMA builtin or register staging).
@@ -685,14 +934,32 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
 
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream) {
     if (a.batch <= 0) return hipSuccess;
-    if (variant < 0 || variant > 5) return hipErrorInvalidValue;
+    if (variant >= 10 && variant < 138 && ring.kind == kRingFp) {
+        // diagnostic builds: variant = 10 + ABL
+        const int nt = col_tiles(a.out_cols), mt = (a.rows + 255) / 256;
+        const long blocks = (((long)a.batch * nt + 7) / 8) * 8 * mt;
+        dim3 grid((unsigned)blocks);
+#define GSW_ABL(N)                                                                                             \
+    case 10 + N:                                                                                               \
+        hipLaunchKernelGGL(binlimb_gemm16_ablate<N>, grid, dim3(256), pipe_lds_bytes<4>(), stream, a, ring.ell, \
+                           ring.mask, nt, mt);                                                                 \
+        break;
+        switch (variant) {
+            GSW_ABL(1) GSW_ABL(2) GSW_ABL(3) GSW_ABL(4) GSW_ABL(8) GSW_ABL(12) GSW_ABL(15) GSW_ABL(16) GSW_ABL(33) GSW_ABL(65)
+            default: return hipErrorInvalidValue;
+        }
+#undef GSW_ABL
+        return hipGetLastError();
+    }
+    if (variant < 0 || variant > 7) return hipErrorInvalidValue;
     if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
-    const int tile_rows = (variant == 1 || variant == 5) ? 512 : 256;
+    const int tile_rows = (variant == 1 || variant == 5 || variant == 7) ? 512 : 256;
     const int nt = col_tiles(a.out_cols);
     const int mt = (a.rows + tile_rows - 1) / tile_rows;
     const long units = (long)a.batch * nt;
     const long groups = (units + 7) / 8;
-    const long blocks = groups * 8 * mt;
+    // variants 4..7 place whole batch entries per XCD (map_workgroup_blocked), the others column tiles
+    const long blocks = variant >= 4 ? (((long)a.batch + 7) / 8) * 8 * nt * mt : groups * 8 * mt;
     if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
     const bool fp = ring.kind == kRingFp;
@@ -719,9 +986,17 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
             if (fp) GSW_LAUNCH((binlimb_gemm16_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
             else GSW_LAUNCH((binlimb_gemm16_pipelined<kRingZpow2, 4>), 256, pipe_lds_bytes<4>());
             break;
-        default:
+        case 5:
             if (fp) GSW_LAUNCH((binlimb_gemm16_pipelined<kRingFp, 8>), 512, pipe_lds_bytes<8>());
             else GSW_LAUNCH((binlimb_gemm16_pipelined<kRingZpow2, 8>), 512, pipe_lds_bytes<8>());
+            break;
+        case 6:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_rowblock<kRingFp, 4>), 256, rowblock_lds_bytes<4>());
+            else GSW_LAUNCH((binlimb_gemm16_rowblock<kRingZpow2, 4>), 256, rowblock_lds_bytes<4>());
+            break;
+        default:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_rowblock<kRingFp, 8>), 512, rowblock_lds_bytes<8>());
+            else GSW_LAUNCH((binlimb_gemm16_rowblock<kRingZpow2, 8>), 512, rowblock_lds_bytes<8>());
             break;
     }
 #undef GSW_LAUNCH
