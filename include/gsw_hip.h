@@ -161,6 +161,13 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch,
                      uint64_t *d_digests);
 
+/* Profiling aid, no counterpart in the reference: streams `bytes` (a multiple of 64 KiB) of d_src once
+ * through the contraction's own LDS-DMA load instruction -- mode 0: 1 KiB contiguous per wave
+ * instruction (right-operand pattern); mode 1: 16 rows x 64 B at `pitch` bytes (left-operand pattern,
+ * which spans bytes / 64 * pitch bytes of d_src) -- so that rocprofv3's FETCH_SIZE can be calibrated
+ * on a known byte count in those patterns.  src_bytes is the size of the buffer behind d_src. */
+int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size_t bytes, int mode, size_t pitch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,7 @@ SIGNATURES = {
     "gsw_fill_uniform": (_i, [_vp, _u64, _u64, _u64, _u64, _i, _vp, _sz]),
     "gsw_sample_naive": (_i, [_vp, _u64, _u64, _vp, _sz]),
     "gsw_sample_gaussian": (_i, [_vp, _u64, _u64, _dbl, _vp, _sz]),
+    "gsw_diag_stream_read": (_i, [_vp, _vp, _sz, _sz, _i, _sz]),
     "gsw_digest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _vp]),
 }
 

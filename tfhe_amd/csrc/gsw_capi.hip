@@ -726,6 +726,18 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
     return GSW_OK;
 }
 
+int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size_t bytes, int mode, size_t pitch) {
+    if (!ctx || !d_src || (bytes & 0xFFFF) || mode < 0 || mode > 1) return fail(GSW_E_INVALID, "bad argument");
+    if (!aligned16(d_src)) return fail(GSW_E_INVALID, "source must be 16-byte aligned");
+    if (mode == 1 && (pitch < 64 || (pitch & 15))) return fail(GSW_E_INVALID, "bad pitch");
+    // the kernel touches [0, bytes) in mode 0 and rows 0 .. bytes/64 - 1 of `pitch` bytes in mode 1
+    const size_t span = mode == 0 ? bytes : (bytes / 64) * pitch;
+    if (span > src_bytes) return fail(GSW_E_INVALID, "source buffer too small: needs %zu bytes, has %zu", span, src_bytes);
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_stream_read(d_src, bytes, mode, pitch, ctx->stream));
+    return GSW_OK;
+}
+
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch, uint64_t *d_digests) {
     if (!ctx || !d_x || !d_digests || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;

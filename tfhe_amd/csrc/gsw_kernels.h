@@ -100,6 +100,8 @@ hipError_t launch_random_words(uint64_t seed, uint64_t stream_id, uint32_t *out,
                                int ell, int last_bits, int batch, size_t stride, hipStream_t stream);
 hipError_t launch_sample_table(const RingDesc &ring, uint64_t seed, uint64_t stream_id, const uint64_t *cum,
                                int table_len, int kmax, uint32_t *out, size_t count, hipStream_t stream);
+// counter calibration (see stream_read_kernel)
+hipError_t launch_stream_read(const void *src, size_t bytes, int mode, size_t pitch, hipStream_t stream);
 hipError_t launch_digest(const uint32_t *x, size_t stride, size_t count, int batch, unsigned long long *digests,
                          hipStream_t stream);
 

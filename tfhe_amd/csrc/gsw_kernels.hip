@@ -856,6 +856,30 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_ablate(GemmArgs p, int 
     else gemm16_pipelined_body<kRingFp, 4, false, ABL>(p, ell, mask, b, nt, mt, smem);
 }
 
+// Counter calibration: streams `bytes` (a multiple of 64 KiB) once through the same LDS-DMA instruction
+// the contraction uses, 1 KiB per wave instruction (mode 0) or 16 rows x 64 B at `pitch` bytes (mode 1),
+// so that FETCH_SIZE can be compared with a known byte count in the kernel's own access patterns.
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint8_t *src, size_t bytes, int mode, size_t pitch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+    const size_t pieces = bytes / 1024;
+    const size_t stride = (size_t)gridDim.x * 4;
+    for (size_t piece = (size_t)blockIdx.x * 4 + wave; piece < pieces; piece += stride) {
+        const uint8_t *g = mode == 0 ? src + piece * 1024 + lane * 16
+                                     : src + (piece * 16 + (lane >> 2)) * pitch + (lane & 3) * 16;
+        lds_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+hipError_t launch_stream_read(const void *src, size_t bytes, int mode, size_t pitch, hipStream_t stream) {
+    hipLaunchKernelGGL(stream_read_kernel, dim3(2048), dim3(256), 4096, stream, (const uint8_t *)src, bytes, mode,
+                       pitch);
+    return hipGetLastError();
+}
+
 // ---- simple kernel: two LDS buffers, compiler-managed waits (LDS-DMA builtin or register staging).
 // Kept as the straightforward form of the same contraction, for A/B timing and as a cross-check.
 
