@@ -69,13 +69,15 @@ def algorithmic_bytes(big_n: int, n: int) -> float:
     return 3.0 * big_n * (n + 1) * 4
 
 
-def load_traffic(workload: str):
-    """HBM bytes per contraction launch from the committed rocprofv3 PMC passes, if any."""
+def load_traffic(workload: str, products_per_launch: float):
+    """HBM-side bytes per contraction launch: the per-product figure of the committed rocprofv3 PMC
+    passes (profiles/pmc_traffic.json, corrected as described there) times the launch size."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload)
-    except (OSError, ValueError):
+            entry = json.load(f).get(workload)
+        return None if entry is None else entry["bytes_per_product"] * products_per_launch
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -209,7 +211,8 @@ def main():
                        "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload),
+                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, mults_per_launch) if variant == DEFAULT_VARIANT else None,
+                "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
                 "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
                 "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} (wrong results by design)"),
                 "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
