@@ -1,0 +1,143 @@
+// The reference's own unit tests (src/gsw/gsw_impl.rs:150-219, src/gsw/sk.rs:37-44) and the untested
+// operations (mult / nand / add / mult_const, checked by decryption) run against the C++ mirror of
+// `FheScheme` (include/gsw_hip.hpp) on a real GPU.  Exit code 0 = all passed.
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+
+#include "gsw_hip.hpp"
+
+using namespace gsw;
+
+static int failures = 0;
+#define EXPECT(cond)                                                         \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+            ++failures;                                                      \
+        }                                                                    \
+    } while (0)
+
+template <class F>
+static bool throws_with(F &&f, const char *needle) {
+    try {
+        f();
+    } catch (const std::runtime_error &e) {
+        return std::string(e.what()).find(needle) != std::string::npos;
+    }
+    return false;
+}
+
+// gsw_impl.rs:209-219 test_inputs
+template <class R>
+static void test_inputs(GSW<R> &fhe) {
+    auto keys = fhe.keygen();
+    DMatrix enc0 = fhe.encrypt(keys.second, 0);
+    EXPECT(fhe.decrypt(keys.first, enc0) == 0);
+    DMatrix enc1 = fhe.encrypt(keys.second, 1);
+    EXPECT(fhe.decrypt(keys.first, enc1) == 1);
+}
+
+static void sk_pk_invariant() {  // gsw_impl.rs:150-163: pk_matrix * s == e
+    GSW<Fp> fhe(10, 10 * Fp::Num_Bits, Sampler::Naive, 1);
+    auto keys = fhe.keygen();
+    const GswSk &sk = keys.first;
+    const GswPk &pk = keys.second;
+    const int m = pk.pk_matrix.rows;
+    for (int i = 0; i < m; ++i) {
+        uint64_t acc = 0;
+        for (int j = 0; j < pk.pk_matrix.cols; ++j) acc = (acc + (uint64_t)Fp::mul(pk.pk_matrix(i, j), sk.s[j])) % Fp::P;
+        EXPECT(acc <= (Fp::P >> 15));  // the NaiveSampler's range (error_sampling.rs:75-79)
+    }
+}
+
+static void test_v_decomp() {  // sk.rs:37-44
+    GSW<Fp> fhe(5, 5 * 31);
+    GswSk sk = fhe.make_sk({3, 1, 4, 1, 5});
+    for (int i = 0; i < Fp::Num_Bits; ++i) EXPECT(sk.v[i] == (1u << i));
+}
+
+static void encryption_decryption_naive() {  // gsw_impl.rs:165-174
+    GSW<Fp> fhe(10, 10 * Fp::Num_Bits, Sampler::Naive, 2);
+    test_inputs(fhe);
+}
+
+static void encryption_decryption_discr_gaussian() {  // gsw_impl.rs:177-186
+    GSW<Zpow2<30>> fhe(10, 10 * 30, Sampler::DiscrGaussian, 3);
+    test_inputs(fhe);
+}
+
+static void encryption_decryption_pow_of_two() {  // gsw_impl.rs:189-207
+    GSW<Zpow2<31>> fhe(10, 10 * 31, Sampler::DiscrGaussian, 4);
+    auto keys = fhe.keygen();
+    const uint32_t msgs[] = {0x12345678u, 0x7FFFFFFEu, 1u, 0u, 0x2AAAAAAAu};
+    for (uint32_t msg : msgs) {
+        DMatrix enc = fhe.encrypt(keys.second, msg);
+        EXPECT(fhe.mp_decrypt(keys.first, enc) == msg);
+    }
+}
+
+static void mult_nand_add_on_reference_format() {
+    // the reference's dense ciphertexts (BitDecomp(R*A) + mu*I) through the dense product of
+    // gsw_impl.rs:107; sigma = 1 errors (the NaiveSampler's noise does not survive a product)
+    GSW<Fp> fhe(3, 93, Sampler::DiscrGaussian, 5);
+    auto keys = fhe.keygen();
+    for (int mu1 = 0; mu1 < 2; ++mu1)
+        for (int mu2 = 0; mu2 < 2; ++mu2) {
+            DMatrix c1 = fhe.encrypt(keys.second, mu1), c2 = fhe.encrypt(keys.second, mu2);
+            EXPECT(fhe.decrypt(keys.first, fhe.mult(c1, c2)) == (uint32_t)(mu1 * mu2));
+            EXPECT(fhe.decrypt(keys.first, fhe.nand(c1, c2)) == (uint32_t)(1 - mu1 * mu2));
+        }
+    DMatrix c1 = fhe.encrypt(keys.second, 1);
+    DMatrix twice = fhe.add(c1, c1);
+    DMatrix scaled = c1;
+    fhe.mult_const(scaled, 2);
+    EXPECT(twice == scaled);  // C + C == 2 * C entrywise (gsw_impl.rs:87-101)
+}
+
+static void gadget_path_equals_dense_product_of_flattened_operands() {
+    GSW<Fp> fhe(3, 93, Sampler::DiscrGaussian, 6);
+    auto keys = fhe.keygen();
+    CompactCiphertext a = fhe.encrypt_compact(keys.second, 1), b = fhe.encrypt_compact(keys.second, 1);
+    CompactCiphertext prod = fhe.mult(a, b), nd = fhe.nand(a, b);
+    EXPECT(fhe.decrypt(keys.first, prod) == 1);
+    EXPECT(fhe.decrypt(keys.first, nd) == 0);
+    // gsw_impl.rs:107 on the dense forms, then the linear BitDecomp^-1, is the same compact ciphertext
+    DMatrix dense = fhe.mult(fhe.to_dense(a), fhe.to_dense(b));
+    CompactCiphertext via_dense = fhe.flatten_to_compact(dense);
+    EXPECT(fhe.to_dense(via_dense) == fhe.to_dense(prod));
+    EXPECT(fhe.decrypt(keys.first, fhe.to_dense(prod)) == 1);
+}
+
+static void panics_of_the_reference() {
+    GSW<Fp> fhe(2, 62);
+    EXPECT(throws_with([&] { fhe.mult(DMatrix(3, 3), DMatrix(4, 4)); }, "different sizes"));       // gsw_impl.rs:105-106
+    EXPECT(throws_with([&] { fhe.add(DMatrix(3, 3), DMatrix(3, 4)); }, "different sizes"));        // gsw_impl.rs:88-89
+    EXPECT(throws_with([&] { fhe.make_pk({1, 2, 3, 4}, 2, 2, {1}, {1, 2}); }, "Dimension Mismatch"));  // pk.rs:24-25
+    auto keys = fhe.keygen();
+    DMatrix c = fhe.encrypt(keys.second, 1);
+    EXPECT(throws_with([&] { fhe.mp_decrypt(keys.first, c); }, "Only supported for pow2 rings"));  // gsw_impl.rs:69
+    GSW<Zpow2<32>> wide(4, 128);
+    EXPECT(throws_with([&] { wide.keygen(); }, "max <= P"));  // error_sampling.rs:21 via gsw_impl.rs:18
+    GSW<Zpow2<32>> wide_ok(4, 128, Sampler::DiscrGaussian, 7, 0, /*check_max=*/false);
+    test_inputs(wide_ok);
+}
+
+int main() {
+    try {
+        sk_pk_invariant();
+        test_v_decomp();
+        encryption_decryption_naive();
+        encryption_decryption_discr_gaussian();
+        encryption_decryption_pow_of_two();
+        mult_nand_add_on_reference_format();
+        gadget_path_equals_dense_product_of_flattened_operands();
+        panics_of_the_reference();
+    } catch (const std::exception &e) {
+        std::printf("FAIL: unexpected exception: %s\n", e.what());
+        return 2;
+    }
+    std::printf(failures ? "%d check(s) failed\n" : "all host-API checks passed\n", failures);
+    return failures ? 1 : 0;
+}
