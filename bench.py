@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
     ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..5 (default 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
 
 
