@@ -53,6 +53,9 @@ struct gsw_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;
+    hipStream_t aux_stream;  // right-operand preparation of chunk k+1 runs here beside chunk k's contraction
+    hipEvent_t ev_entry, ev_prep[2], ev_gemm[2];
+    int overlap_chunk;       // products per pipelined chunk; 0 = one stream, workspace-sized chunks
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
@@ -73,6 +76,7 @@ int ensure_workspace(gsw_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return GSW_OK;
     if (ctx->ws) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
         HIP_TRY(hipFree(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
@@ -85,17 +89,18 @@ int ensure_workspace(gsw_ctx *ctx, size_t bytes) {
 struct ScopedTimer {
     gsw_ctx *ctx;
     int which;
+    hipStream_t stream;
     TimedLaunch t{};
     bool on;
-    ScopedTimer(gsw_ctx *c, int w) : ctx(c), which(w), on(c->timing) {
+    ScopedTimer(gsw_ctx *c, int w, hipStream_t s) : ctx(c), which(w), stream(s), on(c->timing) {
         if (on) {
             if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) on = false;
-            else hipEventRecord(t.start, ctx->stream);
+            else hipEventRecord(t.start, stream);
         }
     }
     ~ScopedTimer() {
         if (on) {
-            hipEventRecord(t.stop, ctx->stream);
+            hipEventRecord(t.stop, stream);
             ctx->timed[which].push_back(t);
         }
     }
@@ -120,14 +125,14 @@ int check_gemm_common(const gsw_ctx *ctx, const void *lhs, size_t stride1, const
 }
 
 int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &a) {
-    ScopedTimer timer(ctx, 0);
+    ScopedTimer timer(ctx, 0, ctx->stream);
     HIP_TRY(gswk::launch_gemm(ctx->ring, a, ctx->gemm_variant, ctx->stream));
     return GSW_OK;
 }
 
-int run_prepare(gsw_ctx *ctx, const gswk::PrepArgs &a) {
-    ScopedTimer timer(ctx, 1);
-    HIP_TRY(gswk::launch_prepare(ctx->ring, a, ctx->stream));
+int run_prepare(gsw_ctx *ctx, const gswk::PrepArgs &a, hipStream_t stream) {
+    ScopedTimer timer(ctx, 1, stream);
+    HIP_TRY(gswk::launch_prepare(ctx->ring, a, stream));
     return GSW_OK;
 }
 
@@ -198,11 +203,19 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&ctx->ev_prep[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gemm[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         delete ctx;
-        return fail(GSW_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        return fail(GSW_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    ctx->overlap_chunk = 128;
+    if (const char *v = getenv("GSW_OVERLAP_CHUNK")) ctx->overlap_chunk = atoi(v) > 0 ? atoi(v) : 0;
     *out = ctx;
     return GSW_OK;
 }
@@ -211,12 +224,19 @@ void gsw_ctx_destroy(gsw_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
     for (auto &v : ctx->timed)
         for (auto &t : v) {
             (void)hipEventDestroy(t.start);
             (void)hipEventDestroy(t.stop);
         }
     if (ctx->ws) (void)hipFree(ctx->ws);
+    (void)hipEventDestroy(ctx->ev_entry);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventDestroy(ctx->ev_prep[i]);
+        (void)hipEventDestroy(ctx->ev_gemm[i]);
+    }
+    (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -225,6 +245,7 @@ int gsw_ctx_set_stream(gsw_ctx *ctx, void *hip_stream) {
     if (!ctx) return fail(GSW_E_INVALID, "null context");
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return GSW_OK;
 }
@@ -276,6 +297,7 @@ int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launche
     if (!ctx || which < 0 || which > 1 || !total_ms || !launches) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->aux_stream));
     double total = 0.0;
     for (auto &t : ctx->timed[which]) {
         float ms = 0.f;
@@ -414,7 +436,8 @@ int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uin
 
 // ---- the hot path ----
 
-int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch) {
+static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch,
+                          hipStream_t stream) {
     if (!ctx || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (batch == 0) return GSW_OK;
     if (!d_c2c || !d_prepared || !aligned16(d_prepared)) return fail(GSW_E_INVALID, "null or unaligned operand");
@@ -432,7 +455,12 @@ int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void
     a.batch = batch;
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
-    return run_prepare(ctx, a);
+    return run_prepare(ctx, a, stream);
+}
+
+int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch) {
+    if (!ctx) return fail(GSW_E_INVALID, "bad argument");
+    return prepare_rhs_on(ctx, d_c2c, stride_c2c, d_prepared, batch, ctx->stream);
 }
 
 static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
@@ -478,16 +506,42 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
     if (int rc = use_device(ctx)) return rc;
     if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, sizeof(uint64_t) * (size_t)batch, ctx->stream));
     const size_t prep = gsw_ctx_prepared_bytes(ctx);
-    // a shared right operand (stride 0) is prepared once; otherwise work in workspace-sized chunks
-    const bool shared = stride2 == 0;
-    size_t chunk = shared ? 1 : ctx->ws_limit / prep;
-    if (chunk < 1) chunk = 1;
-    if (chunk > (size_t)batch) chunk = (size_t)batch;
-    if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
-    if (shared) {
+    if (stride2 == 0) {
+        // a shared right operand is prepared once
+        if (int rc = ensure_workspace(ctx, prep)) return rc;
         if (int rc = gsw_prepare_rhs(ctx, d_c2c, 0, ctx->ws, 1)) return rc;
         return mul_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags, d_digests);
     }
+    size_t pipe_chunk = (size_t)ctx->overlap_chunk;
+    if (pipe_chunk > ctx->ws_limit / (2 * prep)) pipe_chunk = ctx->ws_limit / (2 * prep);
+    if (pipe_chunk >= 1 && (size_t)batch > pipe_chunk) {
+        // Two-stage pipeline over chunks: the (HBM-bound) preparation of chunk k+1 runs on the auxiliary
+        // stream beside the (MFMA-bound) contraction of chunk k; two workspace halves, events for the
+        // hand-offs in both directions, no host synchronisation.
+        if (int rc = ensure_workspace(ctx, 2 * pipe_chunk * prep)) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
+        size_t k = 0;
+        for (size_t b0 = 0; b0 < (size_t)batch; b0 += pipe_chunk, ++k) {
+            const int cur = (int)((size_t)batch - b0 < pipe_chunk ? (size_t)batch - b0 : pipe_chunk);
+            const int half = (int)(k & 1);
+            uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
+            if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
+            if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, ws, cur, ctx->aux_stream)) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
+            if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, ws, prep, d_out + b0 * stride_out, stride_out,
+                                      cur, flags, d_digests ? d_digests + b0 : nullptr))
+                return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
+        }
+        return GSW_OK;
+    }
+    // one stream, workspace-sized chunks
+    size_t chunk = ctx->ws_limit / prep;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)batch) chunk = (size_t)batch;
+    if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
     for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
         const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
         if (int rc = gsw_prepare_rhs(ctx, d_c2c + b0 * stride2, stride2, ctx->ws, cur)) return rc;
@@ -538,7 +592,7 @@ int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepare
         a.batch = 1;
         a.packed_tail = ctx->packed_tail;
         a.layout16 = ctx->gemm_variant >= 4;
-        rc = run_prepare(ctx, a);
+        rc = run_prepare(ctx, a, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(tmp);
