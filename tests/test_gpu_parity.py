@@ -380,3 +380,71 @@ def test_n256_full_product_and_decrypt_after_mul(oracle, tfhe_amd):
     _assert_equal(hp[0], og.mul_gadget(h1[0], h2[0]), "full n=256 product")
     osk = oracle.SecretKey(sk.t, sk.s, sk.v)
     assert og.noise(osk, hp[0], 1) < ring_o.q // 4 // 1000
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z32"])
+def test_n512_real_key_decrypt_after_mul(oracle, tfhe_amd, ring_name):
+    """n = 512 (N = 15903 / 16416): real key, real encryptions, decrypt-after-mul and -nand on 8 products,
+    sampled rows of one product against the oracle.  q = 2^32 needs check_max=False: the reference's
+    keygen asserts max <= P there (error_sampling.rs:21)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    n = 512
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=512, check_max=False)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    sk, pk = gsw.keygen()
+    mu1 = [1, 1, 0, 0, 1, 1, 0, 1]
+    mu2 = [1, 0, 1, 0, 1, 1, 1, 0]
+    c1, c2 = gsw.encrypt_batch(pk, mu1), gsw.encrypt_batch(pk, mu2)
+    assert gsw.decrypt_batch(sk, c1).tolist() == mu1
+    prod, nand = gsw.mult(c1, c2), gsw.nand(c1, c2)
+    assert gsw.decrypt_batch(sk, prod).tolist() == [a * b for a, b in zip(mu1, mu2)]
+    assert gsw.decrypt_batch(sk, nand).tolist() == [1 - a * b for a, b in zip(mu1, mu2)]
+    h1 = tfhe_amd.Ciphertext(gsw.engine, 1, None)
+    rows = [0, 31, 255, 256, 8191, ring_o.big_n(n) - 1]
+    a = c1.to_compact()[3]
+    b = c2.to_compact()[3]
+    got = prod.to_compact()[3]
+    del h1
+    _sampled_rows_check(oracle, og, a, b, got, rows, f"real ciphertexts {ring_name} n=512")
+    osk = oracle.SecretKey(sk.t, sk.s, sk.v)
+    noise = og.noise(osk, prod.to_compact()[0], 1)
+    print(f"\n[{ring_name} n=512] noise after one product: {noise} (q/4 = {ring_o.q // 4})")
+    assert noise < ring_o.q // 4 // 1000
+
+
+def test_depth8_chain_n256(oracle, tfhe_amd):
+    """Depth-8 chain acc <- mult(acc, fresh_i) at n = 256 with a real key: every level decrypts, sampled
+    rows of every level match the oracle run on the same inputs, and the measured noise of row ell-1 is
+    logged against an additive estimate and stays far below q/4.
+
+    Estimate per level: G^-1(acc) has about N/2 ones and multiplies the fresh noise R_i * e, whose
+    entries share the mean (sum of e) / 2 because e is one fixed vector of the public key; hence
+    |bias| ~ (N/2) * |sum e| / 2 plus a fluctuation of about sqrt(N/2) * sqrt(m/4)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 256
+    m = n * 31
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=4096)
+    og = oracle.GSW(ring_o, n, m)
+    sk, pk = gsw.keygen()
+    osk = oracle.SecretKey(sk.t, sk.s, sk.v)
+    big_n = ring_o.big_n(n)
+    e = oracle.matmul(ring_o, pk.pk_matrix, sk.s.reshape(-1, 1)).reshape(-1).astype(np.int64)
+    e = np.where(e > ring_o.q // 2, e - ring_o.q, e)
+    per_level = (big_n / 2) * abs(int(e.sum())) / 2 + 6 * (big_n / 2 * m / 4) ** 0.5
+    for msgs in ([1] * 9, [1, 1, 1, 1, 0, 1, 1, 1, 1]):
+        fresh = gsw.encrypt_batch(pk, msgs)
+        host = fresh.to_compact()
+        acc = tfhe_amd.Ciphertext.from_compact(gsw.engine, host[0])
+        want = msgs[0]
+        prev = host[0]
+        for i in range(1, 9):
+            acc = gsw.mult(acc, tfhe_amd.Ciphertext.from_compact(gsw.engine, host[i]))
+            want *= msgs[i]
+            assert gsw.decrypt(sk, acc) == want
+            cur = acc.to_compact()
+            _sampled_rows_check(oracle, og, prev, host[i], cur, [30, 4000, big_n - 1], f"chain level {i}")
+            noise = og.noise(osk, cur, want)
+            print(f"\n[chain n=256 msgs={msgs}] level {i}: noise {noise}, additive estimate {i * per_level:.0f}, "
+                  f"q/4 = {ring_o.q // 4}")
+            assert noise < 1.5 * i * per_level + 1000 < ring_o.q // 4
+            prev = cur

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsw_hip.so")
+# GSW_HIP_LIBRARY points at an alternative build of the same library (A/B timing of kernel experiments)
+LIB_PATH = os.environ.get("GSW_HIP_LIBRARY") or os.path.join(_HERE, "libgsw_hip.so")
 
 RING_FP_M31 = 0
 RING_ZPOW2 = 1

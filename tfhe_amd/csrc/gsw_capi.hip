@@ -56,6 +56,7 @@ struct gsw_ctx {
     hipStream_t aux_stream;  // right-operand preparation of chunk k+1 runs here beside chunk k's contraction
     hipEvent_t ev_entry, ev_prep[2], ev_gemm[2];
     int overlap_chunk;       // products per pipelined chunk; 0 = one stream, workspace-sized chunks
+    int pass_rows, pass_cols;  // workgroup placement passes (row tiles x column tiles)
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
@@ -124,7 +125,10 @@ int check_gemm_common(const gsw_ctx *ctx, const void *lhs, size_t stride1, const
     return GSW_OK;
 }
 
-int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &a) {
+int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &args) {
+    gswk::GemmArgs a = args;
+    a.pass_rows = ctx->pass_rows;
+    a.pass_cols = ctx->pass_cols;
     ScopedTimer timer(ctx, 0, ctx->stream);
     HIP_TRY(gswk::launch_gemm(ctx->ring, a, ctx->gemm_variant, ctx->stream));
     return GSW_OK;
@@ -215,6 +219,10 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     }
     ctx->stream = ctx->own_stream;
     ctx->overlap_chunk = 128;
+    ctx->pass_rows = 8;
+    ctx->pass_cols = 8;
+    if (const char *v = getenv("GSW_PASS_ROWS")) ctx->pass_rows = atoi(v) > 0 ? atoi(v) : 8;
+    if (const char *v = getenv("GSW_PASS_COLS")) ctx->pass_cols = atoi(v) > 0 ? atoi(v) : 8;
     if (const char *v = getenv("GSW_OVERLAP_CHUNK")) ctx->overlap_chunk = atoi(v) > 0 ? atoi(v) : 0;
     *out = ctx;
     return GSW_OK;

@@ -45,6 +45,7 @@ struct GemmArgs {
     int batch;
     int mode;
     int packed_tail;              // the last column tile is a packed one (see prepared_bytes)
+    int pass_rows, pass_cols;     // placement passes of the blocked workgroup order (row tiles x column tiles)
     unsigned long long *digests;  // optional: digests[b] += digest of the stored tile (zeroed by the caller)
 };
 

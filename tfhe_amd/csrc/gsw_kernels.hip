@@ -301,13 +301,12 @@ __device__ __forceinline__ bool map_workgroup(int batch, int nt_count, int mt_co
 }
 
 // Blocked placement for the 16x16x64 kernels: one batch entry per XCD at a time, its tiles ordered in
-// passes of kPassRows row tiles x kPassCols column tiles.  The 64 workgroups an XCD runs at a time
-// (32 CUs x 2) are then 16 row tiles that share every right-operand panel among them and 4 column
-// tiles that share every left-operand panel, so each byte crosses the fabric into that L2 about
-// once per pass instead of once per workgroup.  Speed only: results do not depend on placement.
-constexpr int kPassRows = 16, kPassCols = 4;
-__device__ __forceinline__ bool map_workgroup_blocked(int batch, int nt_count, int mt_count, int &b, int &nt,
-                                                      int &mt) {
+// passes of pass_rows row tiles x pass_cols column tiles (8 x 8 by default).  The 64 workgroups an XCD
+// runs at a time (32 CUs x 2) then share every right-operand panel among 8 row tiles and every
+// left-operand panel among 8 column tiles, so each byte crosses the fabric into that L2 about once
+// per pass instead of once per workgroup.  Speed only: results do not depend on placement.
+__device__ __forceinline__ bool map_workgroup_blocked(int batch, int nt_count, int mt_count, int kPassRows,
+                                                      int kPassCols, int &b, int &nt, int &mt) {
     const int id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
     const int per = mt_count * nt_count;
@@ -674,7 +673,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmAr
                                                                            int nt_count, int mt_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
     if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
     else gemm16_pipelined_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
 }
@@ -840,7 +839,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_rowblock(GemmArg
                                                                           int nt_count, int mt_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, b, nt, mt)) return;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
     if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
     else gemm16_rowblock_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
 }
