@@ -211,6 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
     uint32_t *out = p.out + (size_t)c.b * p.out_stride;
     unsigned long long dig = 0;
+    const bool want_digest = p.digests != nullptr;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const uint32_t pop = g == 0 ? pop0 : pop1;
@@ -246,7 +247,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
                 }
                 const size_t idx = (size_t)row * p.ld_out + col;
                 out[idx] = val;
-                dig += ((unsigned long long)val + 1ull) * ((2ull * idx + 1ull) * 0x9E3779B97F4A7C15ull);
+                if (want_digest) {
+                        // (x + 1) * (2 idx + 1) as one 32 x 32 -> 64 multiply-add; the constant factor of the
+                        // digest is applied once per wave (multiplication mod 2^64 distributes over the sum)
+                        const unsigned w = 2u * (unsigned)idx + 1u;
+                        dig += (unsigned long long)val * w + w;
+                    }
             }
         }
     }
@@ -258,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
             const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(dig >> 32), off, 64);
             dig += ((unsigned long long)hi << 32) | lo;
         }
-        if (lane == 0) atomicAdd(&p.digests[c.b], dig);
+        if (lane == 0) atomicAdd(&p.digests[c.b], dig * 0x9E3779B97F4A7C15ull);
     }
 }
 
@@ -468,6 +474,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
     uint32_t *out = p.out + (size_t)c.b * p.out_stride;
     unsigned long long dig = 0;
+    const bool want_digest = p.digests != nullptr;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
@@ -512,7 +519,12 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                     }
                     const size_t idx = (size_t)row * p.ld_out + col;
                     out[idx] = val;
-                    dig += ((unsigned long long)val + 1ull) * ((2ull * idx + 1ull) * 0x9E3779B97F4A7C15ull);
+                    if (want_digest) {
+                        // (x + 1) * (2 idx + 1) as one 32 x 32 -> 64 multiply-add; the constant factor of the
+                        // digest is applied once per wave (multiplication mod 2^64 distributes over the sum)
+                        const unsigned w = 2u * (unsigned)idx + 1u;
+                        dig += (unsigned long long)val * w + w;
+                    }
                 }
             }
         }
@@ -524,7 +536,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
             const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(dig >> 32), off, 64);
             dig += ((unsigned long long)hi << 32) | lo;
         }
-        if (lane == 0) atomicAdd(&p.digests[c.b], dig);
+        if (lane == 0) atomicAdd(&p.digests[c.b], dig * 0x9E3779B97F4A7C15ull);
     }
 }
 
