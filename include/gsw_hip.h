@@ -123,6 +123,23 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
                                 size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
                                 uint64_t *d_digests);
 
+/* ---- gate lists over resident ciphertexts: what a caller of mult / nand / add / mult_const
+ *      (gsw_impl.rs:87-123) does next -- chains and NAND circuits -- without the operands leaving
+ *      HBM.  The pool holds n_slots compact ciphertexts slot_stride uint32 apart. ---- */
+#define GSW_GATE_MULT 0u       /* pool[out] = mult(pool[a], pool[b])         gsw_impl.rs:104-111 */
+#define GSW_GATE_NAND 1u       /* pool[out] = nand(pool[a], pool[b])         gsw_impl.rs:114-123 */
+#define GSW_GATE_ADD 2u        /* pool[out] = add(pool[a], pool[b])          gsw_impl.rs:87-94   */
+#define GSW_GATE_MULT_CONST 3u /* pool[out] = b * pool[a], b a ring element  gsw_impl.rs:97-101  */
+typedef struct gsw_gate {
+    uint32_t op, a, b, out;
+} gsw_gate;
+/* Applies the gates with the meaning of running them one after another in list order.  Consecutive
+ * product gates of one kind that do not depend on each other are issued as one batched contraction,
+ * so a levelised circuit costs one launch sequence per level.  A product gate must not name one of
+ * its own operands as its output (GSW_E_INVALID); add and mult_const may work in place. */
+int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
+                     size_t n_gates);
+
 /* ---- encrypt (gsw_impl.rs:27-42): compact form R * pk + message * G, the same contraction
  *      with the N x m random bit matrix as the binary operand ---- */
 /* pk_matrix (pk.rs:28-38), m x (n + 1) row-major tight on the HOST -> prepared device form */

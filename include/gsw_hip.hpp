@@ -243,6 +243,13 @@ class GSW {
         return gadget(c1, c2, GSW_FLAG_NAND);
     }
 
+    // a list of mult / nand / add / mult_const gates over the entries of `pool` (a batch used as slots),
+    // with the meaning of applying them in order; independent products share one batched launch
+    void eval_circuit(CompactCiphertext &pool, const std::vector<gsw_gate> &gates) {
+        check(gsw_eval_circuit(ctx_, pool.buf.u32(), gsw_ctx_compact_elems(ctx_), (uint32_t)pool.batch, gates.data(),
+                               gates.size()));
+    }
+
     // ---- conversions between the reference's dense form and the compact form ----
     // BitDecomp^-1 (linear) of a dense matrix, uploaded as a compact ciphertext
     CompactCiphertext flatten_to_compact(const DMatrix &c) {

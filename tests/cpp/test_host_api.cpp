@@ -110,6 +110,32 @@ static void gadget_path_equals_dense_product_of_flattened_operands() {
     EXPECT(fhe.decrypt(keys.first, fhe.to_dense(prod)) == 1);
 }
 
+static void nand_gates_over_a_pool() {
+    // XOR(a, b) from four NAND gates (gsw_impl.rs:114-123) on slots of one resident pool
+    GSW<Fp> fhe(10, 310, Sampler::DiscrGaussian, 8);
+    auto keys = fhe.keygen();
+    gsw_ctx *ctx = fhe.ctx();
+    const size_t elems = gsw_ctx_compact_elems(ctx);
+    for (uint32_t a = 0; a < 2; ++a)
+        for (uint32_t b = 0; b < 2; ++b) {
+            CompactCiphertext pool{DeviceBuffer(ctx, elems * 4 * 6), 6};
+            check(gsw_memset_zero(ctx, pool.buf.get(), pool.buf.bytes()));
+            std::vector<uint32_t> host(elems);
+            const uint32_t bits[2] = {a, b};
+            for (int k = 0; k < 2; ++k) {
+                CompactCiphertext c = fhe.encrypt_compact(keys.second, bits[k]);
+                c.buf.download(host.data(), elems * 4);
+                check(gsw_memcpy_h2d(ctx, pool.buf.u32() + k * elems, host.data(), elems * 4));
+            }
+            fhe.eval_circuit(pool, {{GSW_GATE_NAND, 0, 1, 2}, {GSW_GATE_NAND, 0, 2, 3}, {GSW_GATE_NAND, 1, 2, 4},
+                                    {GSW_GATE_NAND, 3, 4, 5}});
+            EXPECT(fhe.decrypt(keys.first, pool, 2) == 1 - a * b);
+            EXPECT(fhe.decrypt(keys.first, pool, 5) == (a ^ b));
+        }
+    CompactCiphertext pool{DeviceBuffer(ctx, elems * 4 * 2), 2};
+    EXPECT(throws_with([&] { fhe.eval_circuit(pool, {{GSW_GATE_MULT, 0, 1, 1}}); }, "own operand"));
+}
+
 static void panics_of_the_reference() {
     GSW<Fp> fhe(2, 62);
     EXPECT(throws_with([&] { fhe.mult(DMatrix(3, 3), DMatrix(4, 4)); }, "different sizes"));       // gsw_impl.rs:105-106
@@ -133,6 +159,7 @@ int main() {
         encryption_decryption_pow_of_two();
         mult_nand_add_on_reference_format();
         gadget_path_equals_dense_product_of_flattened_operands();
+        nand_gates_over_a_pool();
         panics_of_the_reference();
     } catch (const std::exception &e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());

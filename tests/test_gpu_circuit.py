@@ -1,0 +1,139 @@
+"""Gate lists over a pool of resident ciphertexts (gsw_eval_circuit) against the oracle applying the
+same gates one after another (gsw_impl.rs:87-123 in compact form), bit exact, plus decryption of
+every output of a NAND circuit built from real encryptions.
+
+The reference holds no vectors for mult/nand/add/mult_const ("parity unpinned"); the oracle's
+restatement and decryption are the checks.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tfhe_amd():
+    import tfhe_amd as pkg
+    from tfhe_amd import _lib
+
+    _lib.lib()  # raises if libgsw_hip.so is missing: there is no fallback
+    return pkg
+
+
+def _apply_on_oracle(oracle, og, pool, gates):
+    """The list's meaning: one gate after another."""
+    pool = pool.copy()
+    shape = pool[0].shape
+    for op, a, b, out in gates:
+        if op == "mult":
+            pool[out] = og.mul_gadget(pool[a], pool[b])
+        elif op == "nand":
+            pool[out] = og.mul_gadget(pool[a], pool[b], flags=oracle.FLAG_NAND)
+        elif op == "add":
+            pool[out] = og.add(pool[a].reshape(1, -1), pool[b].reshape(1, -1)).reshape(shape)
+        else:
+            pool[out] = og.mult_const(pool[a].reshape(1, -1).copy(), b).reshape(shape)
+    return pool
+
+
+def _xor_gates(bits, levelised):
+    """XOR(a_i, b_i) from four NANDs; inputs in slots i and bits+i, result in slot 5*bits+i."""
+    per_bit = []
+    for i in range(bits):
+        a, b, t, u, v, x = i, bits + i, 2 * bits + i, 3 * bits + i, 4 * bits + i, 5 * bits + i
+        per_bit.append([("nand", a, b, t), ("nand", a, t, u), ("nand", b, t, v), ("nand", u, v, x)])
+    if not levelised:
+        return [g for gates in per_bit for g in gates]
+    t = [gates[0] for gates in per_bit]
+    uv = [g for gates in per_bit for g in gates[1:3]]
+    x = [gates[3] for gates in per_bit]
+    return t + uv + x
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z32"])
+def test_xor_circuit_decrypts_and_matches_oracle(oracle, tfhe_amd, ring_name):
+    ring_o, ring_d = {"fp": (oracle.fp(), tfhe_amd.Fp()), "z32": (oracle.zpow2(32), tfhe_amd.Zpow2(32))}[ring_name]
+    n, bits = 10, 4
+    m = n * ring_d.ell
+    # the reference's keygen panics over Zpow2<32> (assert max <= P, error_sampling.rs:21): lifted there
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=77, check_max=ring_name != "z32")
+    og = oracle.GSW(ring_o, n, m)
+    sk, pk = gsw.keygen()
+    a_bits, b_bits = [0, 0, 1, 1], [0, 1, 0, 1]
+    fresh = gsw.encrypt_batch(pk, a_bits + b_bits).to_compact()
+    start = np.zeros((6 * bits,) + fresh.shape[1:], dtype=np.uint32)
+    start[:2 * bits] = fresh
+    expect = None
+    for levelised in (True, False):
+        gates = _xor_gates(bits, levelised)
+        pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+        gsw.eval_circuit(pool, gates)
+        got = pool.to_compact()
+        if expect is None:
+            expect = _apply_on_oracle(oracle, og, start, gates)
+        assert np.array_equal(got, expect), f"levelised={levelised}"
+        out = gsw.decrypt_batch(sk, pool)
+        assert out[5 * bits:].tolist() == [x ^ y for x, y in zip(a_bits, b_bits)]
+        assert out[2 * bits:3 * bits].tolist() == [1 - x * y for x, y in zip(a_bits, b_bits)]
+
+
+def test_gate_list_hazards_follow_list_order(oracle, tfhe_amd):
+    """Random gates with read-after-write, write-after-read and write-after-write between neighbours,
+    in-place adds and constant multiples, on uniform random operands."""
+    ring_o, ring_d = oracle.fp(), tfhe_amd.Fp()
+    n, slots = 3, 12
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=3)
+    og = oracle.GSW(ring_o, n, n * 31)
+    rng = np.random.default_rng(9)
+    start = rng.integers(0, ring_o.q, size=(slots, ring_o.big_n(n), n + 1), dtype=np.uint64).astype(np.uint32)
+    gates = []
+    for _ in range(60):
+        kind = rng.choice(["mult", "nand", "nand", "mult", "add", "mult_const"])
+        a, out = int(rng.integers(slots)), int(rng.integers(slots))
+        if kind == "mult_const":
+            gates.append((kind, a, int(rng.integers(ring_o.q)), out))
+            continue
+        b = int(rng.integers(slots))
+        if kind != "add":
+            while out in (a, b):
+                out = int(rng.integers(slots))
+        gates.append((kind, a, b, out))
+    # explicit neighbours: RAW, WAR, WAW, and a repeated operand
+    gates += [("mult", 0, 1, 2), ("mult", 2, 3, 4), ("nand", 5, 6, 3), ("nand", 7, 8, 3), ("mult", 9, 9, 10)]
+    pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+    gsw.eval_circuit(pool, gates)
+    assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
+    # a second list on the same context reuses the staged slot lists
+    gsw.eval_circuit(pool, gates[:7])
+    twice = _apply_on_oracle(oracle, og, _apply_on_oracle(oracle, og, start, gates), gates[:7])
+    assert np.array_equal(pool.to_compact(), twice)
+
+
+def test_one_level_longer_than_a_pipeline_chunk(oracle, tfhe_amd):
+    """300 independent products in one run: the chunked two-stream path with slot lists."""
+    ring_o, ring_d = oracle.zpow2(30), tfhe_amd.Zpow2(30)
+    n, inputs, count = 2, 10, 300
+    gsw = tfhe_amd.GSW(ring_d, n, n * 30, seed=4)
+    og = oracle.GSW(ring_o, n, n * 30)
+    rng = np.random.default_rng(10)
+    start = np.zeros((inputs + count, ring_o.big_n(n), n + 1), dtype=np.uint32)
+    start[:inputs] = rng.integers(0, ring_o.q, size=(inputs,) + start.shape[1:], dtype=np.uint64).astype(np.uint32)
+    gates = [("mult", int(rng.integers(inputs)), int(rng.integers(inputs)), inputs + (7 * i) % count)
+             for i in range(count)]  # 7 and 300 are coprime: a permutation of the output slots
+    pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+    gsw.eval_circuit(pool, gates)
+    assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
+
+
+def test_bad_gates_are_rejected(tfhe_amd):
+    gsw = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62, seed=1)
+    pool = tfhe_amd.Ciphertext(gsw.engine, 4)
+    with pytest.raises(tfhe_amd.GswError, match="own operand"):
+        gsw.eval_circuit(pool, [("mult", 0, 1, 0)])
+    with pytest.raises(tfhe_amd.GswError, match="out of range"):
+        gsw.eval_circuit(pool, [("nand", 0, 4, 1)])
+    with pytest.raises(tfhe_amd.GswError, match="canonical"):
+        gsw.eval_circuit(pool, [("mult_const", 0, 2147483647, 1)])
+    with pytest.raises(ValueError, match="unknown gate"):
+        gsw.eval_circuit(pool, [("xor", 0, 1, 2)])
+    gsw.eval_circuit(pool, [])

@@ -20,6 +20,15 @@ OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_NOMEM = 0, 1, 2, 3, 4
 
 _vp, _sz, _i, _u32, _u64, _dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_double
 
+
+
+class Gate(C.Structure):
+    """gsw_gate of include/gsw_hip.h"""
+    _fields_ = [("op", _u32), ("a", _u32), ("b", _u32), ("out", _u32)]
+
+
+GATE_MULT, GATE_NAND, GATE_ADD, GATE_MULT_CONST = 0, 1, 2, 3
+
 # every symbol include/gsw_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "gsw_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
@@ -57,6 +66,7 @@ SIGNATURES = {
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch_digest": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint, _vp]),
+    "gsw_eval_circuit": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Gate), _sz]),
     "gsw_prepare_pk": (_i, [_vp, _vp, _vp]),
     "gsw_pack_rbits": (_i, [_vp, _vp, _vp]),
     "gsw_random_rbits": (_i, [_vp, _u64, _u64, _vp, _i]),

@@ -64,6 +64,11 @@ struct gsw_ctx {
     bool packed_tail;  // the last column tile of prepared operands is stored packed
     bool timing;
     std::vector<TimedLaunch> timed[2];
+    // slot lists of gsw_eval_circuit: pinned host staging, device copy, event marking the upload's end
+    uint32_t *h_slots;
+    uint32_t *d_slots;
+    size_t slots_cap;
+    hipEvent_t ev_slots;
 };
 
 namespace {
@@ -209,6 +214,7 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_slots, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&ctx->ev_prep[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gemm[i], hipEventDisableTiming);
@@ -239,7 +245,10 @@ void gsw_ctx_destroy(gsw_ctx *ctx) {
             (void)hipEventDestroy(t.stop);
         }
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
     (void)hipEventDestroy(ctx->ev_entry);
+    (void)hipEventDestroy(ctx->ev_slots);
     for (int i = 0; i < 2; ++i) {
         (void)hipEventDestroy(ctx->ev_prep[i]);
         (void)hipEventDestroy(ctx->ev_gemm[i]);
@@ -445,7 +454,7 @@ int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uin
 // ---- the hot path ----
 
 static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch,
-                          hipStream_t stream) {
+                          hipStream_t stream, const uint32_t *d_slots = nullptr) {
     if (!ctx || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (batch == 0) return GSW_OK;
     if (!d_c2c || !d_prepared || !aligned16(d_prepared)) return fail(GSW_E_INVALID, "null or unaligned operand");
@@ -463,6 +472,7 @@ static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c
     a.batch = batch;
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
+    a.src_slot = d_slots;
     return run_prepare(ctx, a, stream);
 }
 
@@ -473,7 +483,8 @@ int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void
 
 static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
                         size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
-                        uint64_t *d_digests) {
+                        uint64_t *d_digests, const uint32_t *d_lhs_slots = nullptr,
+                        const uint32_t *d_out_slots = nullptr) {
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_prepared || !aligned16(d_prepared) || (stride_prepared_bytes & 15u))
@@ -496,6 +507,8 @@ static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, con
     a.mode = (flags & GSW_FLAG_NAND) ? gswk::kModeNand : gswk::kModeMul;
     a.packed_tail = ctx->packed_tail;
     a.digests = (unsigned long long *)d_digests;
+    a.lhs_slot = d_lhs_slots;
+    a.out_slot = d_out_slots;
     return run_gemm(ctx, a);
 }
 
@@ -506,15 +519,23 @@ int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1,
                         nullptr);
 }
 
+// Slot lists (device arrays of `batch` entries, all three or none): entry b then uses
+// d_c1c + lhs[b] * stride1, d_c2c + rhs[b] * stride2 and d_out + out[b] * stride_out.
+struct SlotLists {
+    const uint32_t *lhs = nullptr, *rhs = nullptr, *out = nullptr;
+    explicit operator bool() const { return lhs != nullptr; }
+};
+
 static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
-                     uint32_t *d_out, size_t stride_out, int batch, unsigned flags, uint64_t *d_digests) {
+                     uint32_t *d_out, size_t stride_out, int batch, unsigned flags, uint64_t *d_digests,
+                     SlotLists slots = SlotLists()) {
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
     if (int rc = use_device(ctx)) return rc;
     if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, sizeof(uint64_t) * (size_t)batch, ctx->stream));
     const size_t prep = gsw_ctx_prepared_bytes(ctx);
-    if (stride2 == 0) {
+    if (stride2 == 0 && !slots) {
         // a shared right operand is prepared once
         if (int rc = ensure_workspace(ctx, prep)) return rc;
         if (int rc = gsw_prepare_rhs(ctx, d_c2c, 0, ctx->ws, 1)) return rc;
@@ -535,11 +556,15 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
             const int half = (int)(k & 1);
             uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
             if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
-            if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, ws, cur, ctx->aux_stream)) return rc;
+            const size_t o = slots ? 0 : b0;  // with slot lists the bases stay put and the lists advance
+            if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ws, cur, ctx->aux_stream,
+                                        slots ? slots.rhs + b0 : nullptr))
+                return rc;
             HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
             HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
-            if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, ws, prep, d_out + b0 * stride_out, stride_out,
-                                      cur, flags, d_digests ? d_digests + b0 : nullptr))
+            if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ws, prep, d_out + o * stride_out, stride_out,
+                                      cur, flags, d_digests ? d_digests + b0 : nullptr,
+                                      slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
                 return rc;
             HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
         }
@@ -552,9 +577,13 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
     if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
     for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
         const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
-        if (int rc = gsw_prepare_rhs(ctx, d_c2c + b0 * stride2, stride2, ctx->ws, cur)) return rc;
-        if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, ctx->ws, prep, d_out + b0 * stride_out,
-                                  stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr))
+        const size_t o = slots ? 0 : b0;
+        if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ctx->ws, cur, ctx->stream,
+                                    slots ? slots.rhs + b0 : nullptr))
+            return rc;
+        if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ctx->ws, prep, d_out + o * stride_out,
+                                  stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr,
+                                  slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
             return rc;
     }
     return GSW_OK;
@@ -570,6 +599,113 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
                                 uint64_t *d_digests) {
     if (!d_digests) return fail(GSW_E_INVALID, "null digest buffer");
     return mul_batch(ctx, d_c1c, stride1, d_c2c, stride2, d_out, stride_out, batch, flags, d_digests);
+}
+
+// ---- gate lists over a pool of resident ciphertexts ----
+
+int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
+                     size_t n_gates) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (n_gates == 0) return GSW_OK;
+    if (!d_pool || !h_gates) return fail(GSW_E_INVALID, "null operand");
+    const size_t elems = gsw_ctx_compact_elems(ctx);
+    if (!aligned16(d_pool) || (slot_stride & 3u) || slot_stride < elems)
+        return fail(GSW_E_INVALID, "pool must be 16-byte aligned with a slot stride >= %zu and a multiple of 4", elems);
+    if (n_gates > (size_t)INT32_MAX) return fail(GSW_E_INVALID, "too many gates");
+    for (size_t i = 0; i < n_gates; ++i) {
+        const gsw_gate &g = h_gates[i];
+        if (g.op > GSW_GATE_MULT_CONST) return fail(GSW_E_INVALID, "gate %zu: unknown op %u", i, g.op);
+        if (g.a >= n_slots || g.out >= n_slots || (g.op != GSW_GATE_MULT_CONST && g.b >= n_slots))
+            return fail(GSW_E_INVALID, "gate %zu: slot out of range (pool has %u)", i, n_slots);
+    }
+    if (int rc = use_device(ctx)) return rc;
+
+    // Schedule: maximal runs of consecutive product gates with one epilogue (mult or nand) in which no
+    // gate reads or overwrites a slot written by an earlier gate of the run, nor writes a slot an
+    // earlier gate of the run reads -- such a run is one batched launch with the list's sequential meaning.
+    struct Run {
+        size_t first, count;  // product gates [first, first+count) of the packed slot lists; count 0 = elementwise gate
+        size_t gate;          // index into h_gates of an elementwise gate
+        unsigned flags;
+    };
+    std::vector<Run> runs;
+    std::vector<uint32_t> lhs, rhs, out;
+    std::vector<uint32_t> read_in(n_slots, 0), written_in(n_slots, 0);  // run number + 1 that touched the slot
+    uint32_t run_id = 0;
+    bool open = false;
+    for (size_t i = 0; i < n_gates; ++i) {
+        const gsw_gate &g = h_gates[i];
+        if (g.op == GSW_GATE_ADD || g.op == GSW_GATE_MULT_CONST) {
+            runs.push_back({0, 0, i, 0});
+            open = false;
+            continue;
+        }
+        const unsigned flags = g.op == GSW_GATE_NAND ? GSW_FLAG_NAND : 0u;
+        const bool hazard = open && (written_in[g.a] == run_id || written_in[g.b] == run_id ||
+                                     written_in[g.out] == run_id || read_in[g.out] == run_id);
+        if (!open || hazard || runs.back().flags != flags) {
+            runs.push_back({lhs.size(), 0, 0, flags});
+            ++run_id;
+            open = true;
+        }
+        if (g.out == g.a || g.out == g.b)
+            return fail(GSW_E_INVALID, "gate %zu: a product cannot overwrite its own operand (slot %u)", i, g.out);
+        lhs.push_back(g.a);
+        rhs.push_back(g.b);
+        out.push_back(g.out);
+        read_in[g.a] = read_in[g.b] = run_id;
+        written_in[g.out] = run_id;
+        ++runs.back().count;
+    }
+
+    const size_t products = lhs.size();
+    if (products) {
+        if (3 * products > ctx->slots_cap) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_slots) HIP_TRY(hipFree(ctx->d_slots));
+            if (ctx->h_slots) HIP_TRY(hipHostFree(ctx->h_slots));
+            ctx->d_slots = nullptr;
+            ctx->h_slots = nullptr;
+            ctx->slots_cap = 0;
+            const size_t cap = 3 * products < 4096 ? 4096 : 3 * products;
+            HIP_TRY(hipMalloc((void **)&ctx->d_slots, cap * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc((void **)&ctx->h_slots, cap * sizeof(uint32_t), hipHostMallocDefault));
+            ctx->slots_cap = cap;
+        } else {
+            HIP_TRY(hipEventSynchronize(ctx->ev_slots));  // the previous upload has left the staging buffer
+        }
+        memcpy(ctx->h_slots, lhs.data(), products * sizeof(uint32_t));
+        memcpy(ctx->h_slots + products, rhs.data(), products * sizeof(uint32_t));
+        memcpy(ctx->h_slots + 2 * products, out.data(), products * sizeof(uint32_t));
+        HIP_TRY(hipMemcpyAsync(ctx->d_slots, ctx->h_slots, 3 * products * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev_slots, ctx->stream));
+    }
+    for (const Run &r : runs) {
+        if (r.count == 0) {
+            const gsw_gate &g = h_gates[r.gate];
+            uint32_t *dst = d_pool + (size_t)g.out * slot_stride;
+            const uint32_t *a = d_pool + (size_t)g.a * slot_stride;
+            if (g.op == GSW_GATE_ADD) {
+                HIP_TRY(gswk::launch_add(ctx->ring, a, d_pool + (size_t)g.b * slot_stride, dst, elems, ctx->stream));
+            } else {
+                if (ctx->ring.kind == gswk::kRingFp ? g.b >= gswk::kFpP : (g.b & ~ctx->ring.mask) != 0)
+                    return fail(GSW_E_INVALID, "gate %zu: constant %u is not a canonical ring element", r.gate, g.b);
+                if (dst != a)
+                    HIP_TRY(hipMemcpyAsync(dst, a, elems * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(gswk::launch_mult_const(ctx->ring, dst, g.b, elems, ctx->stream));
+            }
+            continue;
+        }
+        SlotLists sl;
+        sl.lhs = ctx->d_slots + r.first;
+        sl.rhs = ctx->d_slots + products + r.first;
+        sl.out = ctx->d_slots + 2 * products + r.first;
+        if (int rc = mul_batch(ctx, d_pool, slot_stride, d_pool, slot_stride, d_pool, slot_stride, (int)r.count,
+                               r.flags, nullptr, sl))
+            return rc;
+    }
+    return GSW_OK;
 }
 
 // ---- encrypt ----

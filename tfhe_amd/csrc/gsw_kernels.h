@@ -47,6 +47,10 @@ struct GemmArgs {
     int packed_tail;              // the last column tile is a packed one (see prepared_bytes)
     int pass_rows, pass_cols;     // placement passes of the blocked workgroup order (row tiles x column tiles)
     unsigned long long *digests;  // optional: digests[b] += digest of the stored tile (zeroed by the caller)
+    // optional slot lists (device, `batch` entries): entry b reads lhs + lhs_slot[b] * lhs_stride and writes
+    // out + out_slot[b] * out_stride; null means slot b
+    const uint32_t *lhs_slot;
+    const uint32_t *out_slot;
 };
 
 inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }
@@ -73,6 +77,7 @@ struct PrepArgs {
     int batch;
     int packed_tail;
     int layout16;  // fragment order of the 16x16x64 kernels (variants 4, 5) instead of the 32x32x32 ones
+    const uint32_t *src_slot;  // optional slot list (device, `batch` entries) into src; null means slot b
 };
 
 hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream);

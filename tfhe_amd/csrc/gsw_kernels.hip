@@ -18,6 +18,9 @@
 
 namespace gswk {
 
+// Batch entry b lives in slot slots[b] of its pool (or slot b when no slot list is given).
+__device__ __forceinline__ size_t slot_of(const uint32_t *slots, int b) { return slots ? (size_t)slots[b] : (size_t)b; }
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
     const int e = blockIdx.x, nt = blockIdx.y, b = blockIdx.z;
     const int cidx = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
     const bool packed = a.packed_tail && nt == (int)gridDim.y - 1;
-    const uint32_t *src = a.src + (size_t)b * a.src_stride;
+    const uint32_t *src = a.src + (size_t)slot_of(a.src_slot, b) * a.src_stride;
     const int col = nt * kTileCols + (packed ? (cidx & 7) : cidx);
     uint32_t limb[4] = {0u, 0u, 0u, 0u};
     if (e < a.elems && col < a.cols_valid) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
     const int t = blockIdx.x >> 1, step = blockIdx.x & 1, nt = blockIdx.y, b = blockIdx.z;
     const int cidx = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
     const bool packed = a.packed_tail && nt == (int)gridDim.y - 1;
-    const uint32_t *src = a.src + (size_t)b * a.src_stride;
+    const uint32_t *src = a.src + (size_t)slot_of(a.src_slot, b) * a.src_stride;
     const int col = nt * kTileCols + (packed ? (cidx & 7) : cidx);
 #pragma unroll
     for (int gh = 0; gh < 2; ++gh) {
@@ -209,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
     const int col = c.nt * kTileCols + (NFRAG == 4 ? c32 : (c32 & 7));
     const bool col_owner = NFRAG == 4 ? true : c32 < 8;
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
-    uint32_t *out = p.out + (size_t)c.b * p.out_stride;
+    uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
     unsigned long long dig = 0;
     const bool want_digest = p.digests != nullptr;
 #pragma unroll
@@ -376,7 +379,7 @@ __device__ __forceinline__ void gemm_pipelined_body(const GemmArgs &p, int ell, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
-    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
     const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     int row_load = mt * kRows + tid;
     if (row_load > p.rows - 1) row_load = p.rows - 1;  // clamped rows are computed but never stored
@@ -472,7 +475,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                                                 const v4i (&acc)[4][PACKED ? 2 : 8], const uint32_t (&pop)[4]) {
     const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
-    uint32_t *out = p.out + (size_t)c.b * p.out_stride;
+    uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
     unsigned long long dig = 0;
     const bool want_digest = p.digests != nullptr;
 #pragma unroll
@@ -720,7 +723,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
-    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
     const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     const int stages = p.e4 / kStageElems;
     const bool wave_active = mt * kRows + wave * 64 < p.rows;
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
     int b, nt, mt;
     if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
 
-    const uint32_t *lhs = p.lhs + (size_t)b * p.lhs_stride;
+    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
     const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     int row_load = mt * kTileRows + tid;
     if (row_load > p.rows - 1) row_load = p.rows - 1;  // clamped rows are computed but never stored

@@ -383,6 +383,20 @@ class GSW:
         """src/gsw/gsw_impl.rs:114-123: I - C1 * C2, i.e. G - Pc in compact form."""
         return self._product(c1, c2, FLAG_NAND)
 
+    GATE_OPS = {"mult": 0, "nand": 1, "add": 2, "mult_const": 3}
+
+    def eval_circuit(self, pool: Ciphertext, gates) -> None:
+        """Apply (op, a, b, out) gates over the slots of `pool` (a batch of resident ciphertexts), in list
+        order: op is "mult" / "nand" / "add" / "mult_const" (src/gsw/gsw_impl.rs:87-123; for mult_const
+        b is the constant).  Independent consecutive products run as one batched contraction."""
+        gates = list(gates)
+        arr = (_lib.Gate * len(gates))()
+        for i, (op, ga, gb, out) in enumerate(gates):
+            if op not in self.GATE_OPS:
+                raise ValueError(f"unknown gate op {op!r}")
+            arr[i] = _lib.Gate(self.GATE_OPS[op], int(ga), int(gb), int(out))
+        check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, arr, len(gates)))
+
     # ---- the reference's dense operations on arbitrary matrices ----
     def _dense_binary(self, fn, a, b) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.uint32)
