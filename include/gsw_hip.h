@@ -178,6 +178,33 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch,
                      uint64_t *d_digests);
 
+/* ---- wire format.  The reference has no serialisation (its keys and ciphertexts are in-memory
+ *      nalgebra values: pk.rs:13-16, sk.rs:13-17, gsw_impl.rs:15); this is the canonical form in which
+ *      they travel between hosts or are stored.  All integers little endian:
+ *        0  "GSW1"            4  kind (GSW_WIRE_*)   5  ring kind (GSW_RING_*)   6  bits per element   7  0
+ *        8  n   12  m   16  rows   20  cols   24  entry count   28  0          (u32 each)
+ *       32  count * rows * cols canonical u32 values, row-major, no padding
+ *      end  u64 digest of the payload taken as one entry of gsw_digest_batch
+ *      rows x cols: ciphertext N x (n+1) in compact form (BitDecomp^-1 of the reference's matrix,
+ *      helper.rs:24-49 without the == 1 test); public key m x (n+1) = pk_matrix (pk.rs:28-38);
+ *      secret key 1 x n = t (sk.rs:20-28; s and v are recomputed from it).
+ *      Readers reject a wrong magic, kind, ring, shape or size, non-canonical elements and a digest
+ *      mismatch with GSW_E_INVALID. ---- */
+#define GSW_WIRE_CIPHERTEXT 1
+#define GSW_WIRE_PUBLIC_KEY 2
+#define GSW_WIRE_SECRET_KEY 3
+/* bytes of a wire object of `count` entries (keys: count = 1); 0 for a bad argument */
+size_t gsw_wire_bytes(const gsw_ctx *ctx, int kind, int count);
+/* keys live on the host: pk_matrix (m x (n+1) row-major) or t (n values) */
+int gsw_wire_write_host(gsw_ctx *ctx, int kind, const uint32_t *h_values, void *h_out, size_t out_bytes);
+int gsw_wire_read_host(gsw_ctx *ctx, int kind, const void *h_in, size_t in_bytes, uint32_t *h_values);
+/* device-resident compact ciphertexts <-> wire bytes on the host; with d_cc == NULL the reader only
+ * validates and reports the entry count */
+int gsw_wire_write_compact(gsw_ctx *ctx, const uint32_t *d_cc, size_t stride, int batch, void *h_out,
+                           size_t out_bytes);
+int gsw_wire_read_compact(gsw_ctx *ctx, const void *h_in, size_t in_bytes, uint32_t *d_cc, size_t stride,
+                          int max_batch, int *batch_out);
+
 /* Profiling aid, no counterpart in the reference: streams `bytes` (a multiple of 64 KiB) of d_src once
  * through the contraction's own LDS-DMA load instruction -- mode 0: 1 KiB contiguous per wave
  * instruction (right-operand pattern); mode 1: 16 rows x 64 B at `pitch` bytes (left-operand pattern,

@@ -27,6 +27,7 @@ class Gate(C.Structure):
     _fields_ = [("op", _u32), ("a", _u32), ("b", _u32), ("out", _u32)]
 
 
+WIRE_CIPHERTEXT, WIRE_PUBLIC_KEY, WIRE_SECRET_KEY = 1, 2, 3
 GATE_MULT, GATE_NAND, GATE_ADD, GATE_MULT_CONST = 0, 1, 2, 3
 
 # every symbol include/gsw_hip.h declares: name -> (restype, argtypes)
@@ -78,6 +79,11 @@ SIGNATURES = {
     "gsw_fill_uniform": (_i, [_vp, _u64, _u64, _u64, _u64, _i, _vp, _sz]),
     "gsw_sample_naive": (_i, [_vp, _u64, _u64, _vp, _sz]),
     "gsw_sample_gaussian": (_i, [_vp, _u64, _u64, _dbl, _vp, _sz]),
+    "gsw_wire_bytes": (_sz, [_vp, _i, _i]),
+    "gsw_wire_write_host": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "gsw_wire_read_host": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "gsw_wire_write_compact": (_i, [_vp, _vp, _sz, _i, _vp, _sz]),
+    "gsw_wire_read_compact": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.POINTER(_i)]),
     "gsw_diag_stream_read": (_i, [_vp, _vp, _sz, _sz, _i, _sz]),
     "gsw_digest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _vp]),
 }

@@ -176,6 +176,27 @@ class Ciphertext:
             check(_lib.lib().gsw_download_compact(e.handle, out[b].ctypes.data, self.entry_ptr(b)))
         return out[0] if self.batch == 1 else out
 
+    def to_bytes(self) -> bytes:
+        """The batch as one wire object (include/gsw_hip.h, "wire format")."""
+        e, L = self.engine, _lib.lib()
+        size = L.gsw_wire_bytes(e.handle, _lib.WIRE_CIPHERTEXT, self.batch)
+        out = np.empty(size, dtype=np.uint8)
+        check(L.gsw_wire_write_compact(e.handle, self.ptr, self.stride, self.batch, out.ctypes.data, size))
+        return out.tobytes()
+
+    @classmethod
+    def from_bytes(cls, engine: Engine, data: bytes) -> "Ciphertext":
+        """Validate a wire object against the engine's ring and (n, m) and upload its ciphertexts."""
+        L = _lib.lib()
+        raw = np.frombuffer(data, dtype=np.uint8)
+        count = C.c_int(0)
+        check(L.gsw_wire_read_compact(engine.handle, raw.ctypes.data, raw.size, None, 0, 0, C.byref(count)))
+        ct = cls(engine, max(count.value, 1))
+        ct.batch = count.value
+        check(L.gsw_wire_read_compact(engine.handle, raw.ctypes.data, raw.size, ct.ptr, ct.stride, count.value,
+                                      C.byref(count)))
+        return ct
+
     def to_dense(self, b: int = 0) -> np.ndarray:
         """BitDecomp(Cc): the reference's N x N matrix form (helper.rs:17-21), computed on the GPU."""
         e = self.engine
@@ -276,6 +297,40 @@ class GSW:
             pk.prepared = eng.alloc(eng.pk_prepared_bytes)
             check(L.gsw_prepare_pk(eng.handle, np.ascontiguousarray(pk_matrix).ctypes.data, pk.prepared.ptr))
         return pk
+
+    # ---- keys on the wire ----
+    def _host_object(self, kind: int, values: np.ndarray) -> bytes:
+        L, h = _lib.lib(), self.engine.handle
+        size = L.gsw_wire_bytes(h, kind, 1)
+        out = np.empty(size, dtype=np.uint8)
+        values = np.ascontiguousarray(values, dtype=np.uint32)
+        check(L.gsw_wire_write_host(h, kind, values.ctypes.data, out.ctypes.data, size))
+        return out.tobytes()
+
+    def pk_to_bytes(self, pk: PublicKey) -> bytes:
+        if pk.pk_matrix.shape != (self.m, self.n + 1):
+            raise ValueError("public key was built for different (n, m)")
+        return self._host_object(_lib.WIRE_PUBLIC_KEY, pk.pk_matrix)
+
+    def sk_to_bytes(self, sk: SecretKey) -> bytes:
+        return self._host_object(_lib.WIRE_SECRET_KEY, sk.t)
+
+    def pk_from_bytes(self, data: bytes) -> PublicKey:
+        eng, L = self.engine, _lib.lib()
+        raw = np.frombuffer(data, dtype=np.uint8)
+        mat = np.empty((self.m, self.n + 1), dtype=np.uint32)
+        check(L.gsw_wire_read_host(eng.handle, _lib.WIRE_PUBLIC_KEY, raw.ctypes.data, raw.size, mat.ctypes.data))
+        pk = PublicKey(mat[:, 0].copy(), mat)
+        pk.prepared = eng.alloc(eng.pk_prepared_bytes)
+        check(L.gsw_prepare_pk(eng.handle, mat.ctypes.data, pk.prepared.ptr))
+        return pk
+
+    def sk_from_bytes(self, data: bytes) -> SecretKey:
+        raw = np.frombuffer(data, dtype=np.uint8)
+        t = np.empty(self.n, dtype=np.uint32)
+        check(_lib.lib().gsw_wire_read_host(self.engine.handle, _lib.WIRE_SECRET_KEY, raw.ctypes.data, raw.size,
+                                            t.ctypes.data))
+        return self.make_sk(t)
 
     # ---- FheScheme ----
     def keygen(self):
