@@ -159,6 +159,14 @@ int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, s
 /* GSW_E_UNSUPPORTED for Fp, as the reference panics (gsw_impl.rs:68-70) */
 int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
                          uint32_t *h_messages_out);
+/* Threshold hooks.  The reference's threshold layer shares sk.s among parties (tfhe_gsw_fp.rs:14-18) and
+ * leaves part_dec as todo!() (tfhe_gsw_fp.rs:27-29).  With additive shares s = s_1 + .. + s_k mod q,
+ * party i publishes <row ell-1 of Cc, s_i> (n + 1 share values on the host); the sum of all partials
+ * is the value decrypt applies its quarter-window test to (gsw_impl.rs:48-52,127-131). */
+int gsw_partial_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_share, const uint32_t *d_cc, size_t stride, int batch,
+                              uint32_t *h_partial_out);
+/* h_partials is parties x batch, row per party */
+int gsw_combine_partials(gsw_ctx *ctx, const uint32_t *h_partials, int parties, int batch, uint32_t *h_bits_out);
 /* d_out[i] = <d_mat[i, 0..cols), h_vec> mod q for i < rows (leading dimension ld): the matrix-vector
  * products of keygen (b = B t, pk.rs:26) and of the key invariant pk_matrix * s = e (gsw_impl.rs:159) */
 int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, const uint32_t *h_vec,

@@ -137,3 +137,24 @@ def test_bad_gates_are_rejected(tfhe_amd):
     with pytest.raises(ValueError, match="unknown gate"):
         gsw.eval_circuit(pool, [("xor", 0, 1, 2)])
     gsw.eval_circuit(pool, [])
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z30"])
+def test_partial_decryptions_of_additive_shares_recombine(oracle, tfhe_amd, ring_name):
+    """k parties each hold an additive share of sk.s; the sum of their partial decryptions is the value
+    decrypt tests (gsw_impl.rs:48-52), so the recombined bits equal plain decryption."""
+    ring_d = tfhe_amd.Fp() if ring_name == "fp" else tfhe_amd.Zpow2(30)
+    gsw = tfhe_amd.GSW(ring_d, 10, 10 * ring_d.ell, seed=31)
+    sk, pk = gsw.keygen()
+    msgs = [0, 1, 1, 0, 1]
+    ct = gsw.nand(gsw.encrypt_batch(pk, msgs), gsw.encrypt_batch(pk, [1] * 5))
+    bits, raw = gsw.decrypt_batch(sk, ct, raw=True)
+    assert bits.tolist() == [1 - m for m in msgs]
+    for parties in (1, 2, 5):
+        shares = gsw.share_secret(sk, parties, seed=parties)
+        assert np.array_equal(shares.astype(np.uint64).sum(axis=0) % ring_d.q, sk.s)
+        partials = np.stack([gsw.part_dec(shares[p], ct) for p in range(parties)])
+        assert np.array_equal(partials.astype(np.uint64).sum(axis=0) % ring_d.q, raw)
+        assert gsw.combine_partials(partials).tolist() == bits.tolist()
+    with pytest.raises(ValueError):
+        gsw.part_dec(np.zeros(3), ct)

@@ -74,6 +74,8 @@ SIGNATURES = {
     "gsw_encrypt_batch": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _i]),
     "gsw_decrypt_batch": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "gsw_mp_decrypt_batch": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "gsw_partial_decrypt_batch": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "gsw_combine_partials": (_i, [_vp, _vp, _i, _i, _vp]),
     "gsw_matvec": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "gsw_decrypt_dense": (_i, [_vp, _vp, _vp, _vp]),
     "gsw_fill_uniform": (_i, [_vp, _u64, _u64, _u64, _u64, _i, _vp, _sz]),

@@ -1029,6 +1029,32 @@ int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc
     return GSW_OK;
 }
 
+int gsw_partial_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_share, const uint32_t *d_cc, size_t stride, int batch,
+                              uint32_t *h_partial_out) {
+    if (!ctx || !h_share || !d_cc || !h_partial_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    if (batch == 0) return GSW_OK;
+    if (int rc = use_device(ctx)) return rc;
+    std::vector<uint32_t> raw;
+    if (int rc = row_dots(ctx, h_share, ctx->width, d_cc, stride, ctx->ld, ctx->ring.ell - 1, 1, batch, raw)) return rc;
+    memcpy(h_partial_out, raw.data(), sizeof(uint32_t) * (size_t)batch);
+    return GSW_OK;
+}
+
+int gsw_combine_partials(gsw_ctx *ctx, const uint32_t *h_partials, int parties, int batch, uint32_t *h_bits_out) {
+    if (!ctx || !h_partials || !h_bits_out || parties < 1 || batch < 0) return fail(GSW_E_INVALID, "bad argument");
+    const uint64_t q = ctx->ring.kind == gswk::kRingFp ? (uint64_t)gswk::kFpP : (uint64_t)ctx->ring.mask + 1;
+    for (int b = 0; b < batch; ++b) {
+        uint64_t sum = 0;
+        for (int p = 0; p < parties; ++p) {
+            const uint32_t v = h_partials[(size_t)p * batch + b];
+            if (v >= q) return fail(GSW_E_INVALID, "partial %d of entry %d is not a canonical ring value", p, b);
+            sum = (sum + v) % q;
+        }
+        h_bits_out[b] = is_zero_one(ctx->ring, (uint32_t)sum);  // gsw_impl.rs:127-131 on the recombined value
+    }
+    return GSW_OK;
+}
+
 int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, const uint32_t *h_vec,
                uint32_t *d_out) {
     if (!ctx || !d_mat || !h_vec || !d_out || rows < 0 || cols < 1 || ld < cols) return fail(GSW_E_INVALID, "bad argument");

@@ -390,6 +390,32 @@ class GSW:
         """src/gsw/gsw_impl.rs:48-52."""
         return int(self.decrypt_batch(sk, ct)[0])
 
+    def share_secret(self, sk: SecretKey, parties: int, seed: int = 0) -> np.ndarray:
+        """Additive shares of sk.s (what `setup` of src/tfhe_gsw_fp.rs:14-18 hands to a sharing scheme):
+        parties x (n + 1) values whose column sums are s modulo q."""
+        q = self.ring.q
+        rng = np.random.default_rng(seed)
+        shares = rng.integers(0, q, size=(parties, self.n + 1), dtype=np.uint64)
+        shares[-1] = (sk.s.astype(np.uint64) + (q - shares[:-1].sum(axis=0) % q)) % q
+        return shares.astype(np.uint32)
+
+    def part_dec(self, share: np.ndarray, ct: Ciphertext) -> np.ndarray:
+        """One party's partial decryption (part_dec of src/tfhe_gsw_fp.rs:27-29, a todo!() there)."""
+        share = np.ascontiguousarray(share, dtype=np.uint32)
+        if share.size != self.n + 1:
+            raise ValueError(f"a share of sk.s has n + 1 = {self.n + 1} entries, got {share.size}")
+        out = np.empty(ct.batch, dtype=np.uint32)
+        check(_lib.lib().gsw_partial_decrypt_batch(self.engine.handle, share.ctypes.data, ct.ptr, ct.stride, ct.batch,
+                                                   out.ctypes.data))
+        return out
+
+    def combine_partials(self, partials) -> np.ndarray:
+        partials = np.ascontiguousarray(partials, dtype=np.uint32)
+        parties, batch = partials.shape
+        out = np.empty(batch, dtype=np.uint32)
+        check(_lib.lib().gsw_combine_partials(self.engine.handle, partials.ctypes.data, parties, batch, out.ctypes.data))
+        return out
+
     def mp_decrypt_batch(self, sk: SecretKey, ct: Ciphertext) -> np.ndarray:
         eng = self.engine
         out = np.empty(ct.batch, dtype=np.uint32)
