@@ -16,7 +16,7 @@
  *  - dense:    the reference's `Ciphertext = DMatrix<R>` (gsw_impl.rs:15), N x N with
  *              N = ell * (n + 1), here ROW-MAJOR uint32 (nalgebra is column-major).
  *  - compact:  Cc = BitDecomp^-1_linear(C), N rows x (n + 1) columns, row-major uint32
- *              with leading dimension ld = gsw_ctx_ld() (n + 1 rounded up to 4); the
+ *              with leading dimension ld = gsw_ctx_ld() (n + 1 rounded up to 16); the
  *              padding columns must be zero (every routine here keeps them zero).
  *              BitDecomp(Cc) is the flattened ciphertext; the product of gsw_impl.rs:107
  *              satisfies BitDecomp^-1_linear(C1 * C2) = C1 * C2c, which for a flattened

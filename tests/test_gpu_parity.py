@@ -94,7 +94,7 @@ def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
     for b in range(4):
         _assert_equal(got[b], og.mul_gadget(c1[b], c2), f"broadcast rhs [{b}]")
     raw = out.buf.download(np.uint32, eng.compact_elems * 4).reshape(4, eng.big_n, eng.ld)
-    assert eng.ld == 12 and (raw[:, :, n + 1:] == 0).all()
+    assert eng.ld == 16 and (raw[:, :, n + 1:] == 0).all()
     # digests from the contraction's epilogue == the digest kernel == the oracle's digest of the buffer
     dig = eng.alloc(8 * 4)
     dig2 = eng.alloc(8 * 4)

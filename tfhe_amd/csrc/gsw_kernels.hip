@@ -705,6 +705,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmAr
 // three-buffer ring; loads past the last stage are clamped re-loads so that the counted waits stay
 // static (they land in buffers nobody reads again and are drained before the workgroup ends).
 
+#ifndef GSW_SPREAD_LOADS
+#define GSW_SPREAD_LOADS 1
+#endif
+
 template <int WAVES>
 constexpr int rowblock_lds_bytes() { return 2 * WAVES * 4096 + kPipeBuffers * kStageElems * 4 * kFragBytes; }
 
@@ -751,24 +755,27 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     const int swz = (r16 >> 2) & 3;
     const int word_pair = (lane >> 5) * 8;
 
-    auto issue_lhs = [&](int super_stage) {
+    auto issue_lhs_piece = [&](int super_stage, int rg) {
         int st = super_stage * 4 + ld_j;
         if (st > stages - 1) st = stages - 1;  // past the end: re-load the last stage (never read)
         const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
+        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
     };
-    auto issue_rhs = [&](int t, int buf) {
+    auto issue_lhs = [&](int super_stage) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(super_stage, rg);
+    };
+    auto issue_rhs_round = [&](int t, int buf, int j) {
         if (t > stages - 1) t = stages - 1;
         const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
         const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+        const int piece = (j * WAVES + wave) % kPieces;
+        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+    };
+    auto issue_rhs = [&](int t, int buf) {
 #pragma unroll
-        for (int j = 0; j < kRounds; ++j) {
-            const int piece = (j * WAVES + wave) % kPieces;
-            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
-        }
+        for (int j = 0; j < kRounds; ++j) issue_rhs_round(t, buf, j);
     };
 
     issue_lhs(0);
@@ -781,8 +788,14 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
         // The previous iteration issued kRounds right-operand loads, plus 4 left-operand loads when it
         // opened a super-stage; everything older has landed once only those are pending.
         wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
-        if (kSlot == 0) issue_lhs((t >> 2) + 1);
-        issue_rhs(t + 2, buf == 0 ? 2 : buf - 1);
+        // An active wave spreads this stage's loads between its MFMA groups (same number, same order
+        // class for the counted wait): issued in one burst right after the barrier, the four waves of
+        // the workgroup queue up at the texture addresser while their MFMA pipes sit idle.
+        constexpr bool kSpread = kActive && GSW_SPREAD_LOADS;
+        if (!kSpread) {
+            if (kSlot == 0) issue_lhs((t >> 2) + 1);
+            issue_rhs(t + 2, buf == 0 ? 2 : buf - 1);
+        }
         if constexpr (kActive) {
             const unsigned char *sa = smem + ((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
                                       ((kSlot ^ swz) * 16) + word_pair;
@@ -808,6 +821,18 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
                         fb[cur ^ 1][j] = *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this group's MFMAs
+                if constexpr (kSpread) {
+                    // kGroups groups carry kRounds right-operand rounds and 4 left-operand pieces
+                    constexpr int kLhsPer = 4 / kGroups, kRhsPer = (kRounds + kGroups - 1) / kGroups;
+                    if (kSlot == 0) {
+#pragma unroll
+                        for (int k = 0; k < kLhsPer; ++k) issue_lhs_piece((t >> 2) + 1, grp * kLhsPer + k);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kRhsPer; ++k)
+                        if (grp * kRhsPer + k < kRounds) issue_rhs_round(t + 2, buf == 0 ? 2 : buf - 1, grp * kRhsPer + k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const int step = grp * kGroup / kNB;
                 const int f0 = grp * kGroup - step * kNB;
                 if (f0 == 0) {
