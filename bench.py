@@ -31,11 +31,11 @@ from tfhe_amd import _lib, dist as gdist  # noqa: E402
 
 INT8_DENSE_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 ops/clk x 2.4 GHz (2x the bf16 dense MFMA peak)
 HBM_PEAK_GBS = 8000.0
-DEFAULT_VARIANT = 6
 KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined<8 waves>",
                 2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>",
                 4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>",
-                6: "binlimb_gemm16_rowblock<4 waves>", 7: "binlimb_gemm16_rowblock<8 waves>"}
+                6: "binlimb_gemm16_rowblock<4 waves>", 7: "binlimb_gemm16_rowblock<8 waves>",
+                8: "binlimb_gemm16_stagger"}
 
 WORKLOADS = {
     # name: (ring, n, default batch)
@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
-    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..5 (default 6)")
+    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..8 (default: chosen by shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -69,14 +69,16 @@ def algorithmic_bytes(big_n: int, n: int) -> float:
     return 3.0 * big_n * (n + 1) * 4
 
 
-def load_traffic(workload: str, products_per_launch: float):
+def load_traffic(workload: str, variant: int, products_per_launch: float):
     """HBM-side bytes per contraction launch: the per-product figure of the committed rocprofv3 PMC
     passes (profiles/pmc_traffic.json, corrected as described there) times the launch size."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             entry = json.load(f).get(workload)
-        return None if entry is None else entry["bytes_per_product"] * products_per_launch
+        if entry is None or entry.get("kernel_variant") != variant:
+            return None  # no PMC passes committed for this kernel on this workload
+        return entry["bytes_per_product"] * products_per_launch
     except (OSError, ValueError, KeyError):
         return None
 
@@ -143,9 +145,9 @@ def main():
     batch = args.batch or default_batch
     if args.variant is not None:
         os.environ["GSW_GEMM_VARIANT"] = str(args.variant)
-    variant = int(os.environ.get("GSW_GEMM_VARIANT", DEFAULT_VARIANT))
     gsw = tfhe_amd.GSW(ring, n, n * ring.ell, seed=0x6A5C0000 + rank, device=local_rank)
     eng, L = gsw.engine, _lib.lib()
+    variant = L.gsw_ctx_gemm_variant(eng.handle)  # chosen by shape unless GSW_GEMM_VARIANT says otherwise
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
     big_n, ld, ct = eng.big_n, eng.ld, eng.compact_elems
@@ -211,7 +213,7 @@ def main():
                        "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, mults_per_launch) if variant == DEFAULT_VARIANT else None,
+                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),
                 "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
                 "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
                 "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} (wrong results by design)"),

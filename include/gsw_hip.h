@@ -64,6 +64,7 @@ int gsw_sync(gsw_ctx *ctx);
 int gsw_ctx_ell(const gsw_ctx *ctx);               /* R::Num_Bits (field.rs:39, pow2_ring.rs:19)   */
 int gsw_ctx_big_n(const gsw_ctx *ctx);             /* N = ell * (n + 1) (gsw_impl.rs:28)           */
 int gsw_ctx_ld(const gsw_ctx *ctx);                /* leading dimension of compact ciphertexts      */
+int gsw_ctx_gemm_variant(const gsw_ctx *ctx);      /* contraction kernel in use (GSW_GEMM_VARIANT or chosen by shape) */
 size_t gsw_ctx_compact_elems(const gsw_ctx *ctx);  /* N * ld uint32 per compact ciphertext          */
 size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx); /* bytes of one prepared right operand           */
 size_t gsw_ctx_rbits_elems(const gsw_ctx *ctx);    /* N * ld_r uint32 of packed encryption bits     */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "gsw_ctx_ell": (_i, [_vp]),
     "gsw_ctx_big_n": (_i, [_vp]),
     "gsw_ctx_ld": (_i, [_vp]),
+    "gsw_ctx_gemm_variant": (_i, [_vp]),
     "gsw_ctx_compact_elems": (_sz, [_vp]),
     "gsw_ctx_prepared_bytes": (_sz, [_vp]),
     "gsw_ctx_rbits_elems": (_sz, [_vp]),

@@ -212,12 +212,14 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_limit = (size_t)2 << 30;
-    ctx->gemm_variant = 6;  // 16x16x64 MFMA, 256-row tile, 64-byte left-operand loads
+    // 16x16x64 MFMA with 64-byte left-operand loads: 256-row tiles, two workgroups per CU (6), or for
+    // large N the staggered 512-row tile (8), which halves the right-operand traffic per MFMA
+    ctx->gemm_variant = ctx->big_n >= 12288 ? 8 : 6;
     ctx->timing = false;
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
-    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 7) && !(ctx->gemm_variant >= 10 && ctx->gemm_variant < 138)) {
+    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 8) && !(ctx->gemm_variant >= 10 && ctx->gemm_variant < 138)) {
         delete ctx;
-        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..7");
+        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..8");
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
@@ -286,6 +288,7 @@ int gsw_sync(gsw_ctx *ctx) {
 int gsw_ctx_ell(const gsw_ctx *ctx) { return ctx ? ctx->ring.ell : 0; }
 int gsw_ctx_big_n(const gsw_ctx *ctx) { return ctx ? ctx->big_n : 0; }
 int gsw_ctx_ld(const gsw_ctx *ctx) { return ctx ? ctx->ld : 0; }
+int gsw_ctx_gemm_variant(const gsw_ctx *ctx) { return ctx ? ctx->gemm_variant : -1; }
 size_t gsw_ctx_compact_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld : 0; }
 size_t gsw_ctx_prepared_bytes(const gsw_ctx *ctx) { return ctx ? gswk::prepared_bytes(ctx->width, ctx->e4, ctx->packed_tail) : 0; }
 size_t gsw_ctx_rbits_elems(const gsw_ctx *ctx) { return ctx ? (size_t)ctx->big_n * ctx->ld_r : 0; }

@@ -705,6 +705,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmAr
 // three-buffer ring; loads past the last stage are clamped re-loads so that the counted waits stay
 // static (they land in buffers nobody reads again and are drained before the workgroup ends).
 
+// An 8-byte LDS read that the compiler cannot pair with a neighbour.  Two reads 1 KiB apart would be
+// fused into ds_read2st64_b64, which is serviced in groups of 16 lanes with 32 banks (8 LDS cycles,
+// and 2-way conflicts on the left-operand image) where ds_read_b64 takes 2 cycles conflict free.
+__device__ __forceinline__ uint2 lds_read_b64_alone(uint32_t lds_byte_address) {
+    asm volatile("" : "+v"(lds_byte_address));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((uintptr_t)lds_byte_address);
+    return make_uint2(v.x, v.y);
+}
+
 #ifndef GSW_SPREAD_LOADS
 #define GSW_SPREAD_LOADS 1
 #endif
@@ -797,13 +807,13 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
             issue_rhs(t + 2, buf == 0 ? 2 : buf - 1);
         }
         if constexpr (kActive) {
-            const unsigned char *sa = smem + ((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
-                                      ((kSlot ^ swz) * 16) + word_pair;
+            const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
+                                                  ((kSlot ^ swz) * 16) + word_pair);
             const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16;
             uint2 w[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                w[rg] = *reinterpret_cast<const uint2 *>(sa + rg * 1024);
+                w[rg] = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
                 pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
             }
             constexpr int kGroup = PACKED ? 2 : 4;
@@ -882,6 +892,227 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_rowblock(GemmArg
     if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
     if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
     else gemm16_rowblock_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
+}
+
+// ---- Staggered 512-row tile: 8 waves, one workgroup per CU.
+//
+// Waves w and w + 4 share a SIMD.  Between two barriers the early half (waves 0..3) runs both MFMA
+// steps of stage t; the late half (waves 4..7) runs step 1 of stage t - 1, then step 0 of stage t.
+// Each wave's non-MFMA work (left-operand words, fragment expansion) thus falls into the other
+// wave's MFMA time although one barrier per stage keeps all eight in step.  The late half still
+// reads the buffer of stage t - 1 while stage t + 2 is being loaded, hence a four-deep ring.
+
+constexpr int kStaggerRing = 4;
+constexpr int stagger_lds_bytes() { return 2 * 8 * 4096 + kStaggerRing * kStageElems * 4 * kFragBytes; }
+
+template <int RING, bool PACKED>
+__device__ __forceinline__ void gemm16_stagger_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
+                                                    int mt, unsigned char *smem) {
+    constexpr int WAVES = 8;
+    constexpr int kRows = 64 * WAVES;
+    constexpr int kLhsRing = 2 * WAVES * 4096;
+    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
+    constexpr int kNB = PACKED ? 2 : 8;
+    constexpr int kPieces = 2 * kNB;
+    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
+    constexpr int kGroup = PACKED ? 1 : 4;        // fragments per MFMA group
+    constexpr int kHalfGroups = kNB / kGroup;     // groups per MFMA step (2)
+    constexpr int kQuarters = 2 * kHalfGroups;    // groups per stage: the slots the loads are spread over
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const int stages = p.e4 / kStageElems;
+    const bool wave_active = mt * kRows + wave * 64 < p.rows;
+    const bool late = wave >= 4;
+
+    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
+    const uint32_t *a_row[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
+        if (row > p.rows - 1) row = p.rows - 1;
+        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
+    }
+
+    v4i acc[4][kNB];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int f = 0; f < kNB; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
+    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    const int r16 = lane & 15;
+    const int sh = ((lane >> 4) & 1) * 4;
+    const int swz = (r16 >> 2) & 3;
+    const int word_pair = (lane >> 5) * 8;
+
+    auto issue_lhs_piece = [&](int super_stage, int rg) {
+        int st = super_stage * 4 + ld_j;
+        if (st > stages - 1) st = stages - 1;
+        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
+        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
+    };
+    auto issue_rhs_round = [&](int t, int j) {
+        const int buf = t & (kStaggerRing - 1);
+        if (t > stages - 1) t = stages - 1;
+        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
+        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+        const int piece = (j * WAVES + wave) % kPieces;
+        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+    };
+    // the loads of the epoch that opens stage t, cut into kQuarters portions
+    auto issue_quarter = [&](int t, bool opens_super_stage, int q) {
+        constexpr int kLhsPer = 4 / kQuarters > 0 ? 4 / kQuarters : 1;
+        if (opens_super_stage) {
+#pragma unroll
+            for (int k = 0; k < kLhsPer; ++k)
+                if (q * kLhsPer + k < 4) issue_lhs_piece((t >> 2) + 1, q * kLhsPer + k);
+        }
+        if (q < kRounds) issue_rhs_round(t + 2, q);
+    };
+
+    // one MFMA step (half a stage): fragments [0, kNB) of `step` in the buffer of stage t_data, the
+    // left-operand word of that step per row group, and the load portions q0, q0 + 1, ..
+    auto mfma_step = [&](int step, int t_data, const uint32_t (&word)[4], int t_epoch, bool opens, int q0) {
+        const unsigned char *sb = smem + kLhsRing + (t_data & (kStaggerRing - 1)) * kRhsStage + lane * 16 +
+                                  step * kNB * kFragBytes;
+        v4i fb[2][kGroup];
+        v4i fa[4];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const uint32_t y = word[rg] >> sh;
+            fa[rg][0] = (int)(y & 0x01010101u);
+            fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+            fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+            fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+        }
+#pragma unroll
+        for (int grp = 0; grp < kHalfGroups; ++grp) {
+            const int cur = grp & 1;
+            if (grp + 1 < kHalfGroups) {
+#pragma unroll
+                for (int j = 0; j < kGroup; ++j)
+                    fb[cur ^ 1][j] = *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_quarter(t_epoch, opens, q0 + grp);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    acc[rg][grp * kGroup + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
+                        fa[rg], fb[cur][j], acc[rg][grp * kGroup + j], 0, 0, 0);
+            }
+        }
+    };
+    auto read_words = [&](int t, uint32_t (&wx)[4], uint32_t (&wy)[4]) {
+        const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
+                                              (((t & 3) ^ swz) * 16) + word_pair);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const uint2 w = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
+            wx[rg] = w.x;
+            wy[rg] = w.y;
+            pop[rg] += __popc(w.x) + __popc(w.y);
+        }
+    };
+
+    // prologue: left operand of super-stage 0, right operand of stages 0 and 1
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) issue_rhs_round(0, j);
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, j);
+
+    uint32_t carry[4] = {0u, 0u, 0u, 0u};  // late half: the step-1 words of the previous stage
+    auto epoch = [&](auto slot_tag, auto mode_tag, int t) {
+        constexpr int kSlot = decltype(slot_tag)::value;  // t mod 4
+        constexpr int kMode = decltype(mode_tag)::value;  // 0 inactive, 1 early, 2 late
+        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
+        const bool opens = kSlot == 0;
+        if constexpr (kMode == 0) {
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) issue_quarter(t, opens, q);
+        } else if constexpr (kMode == 1) {
+            uint32_t wx[4], wy[4];
+            read_words(t, wx, wy);
+            mfma_step(0, t, wx, t, opens, 0);
+            mfma_step(1, t, wy, t, opens, kHalfGroups);
+        } else {
+            if constexpr (kMode == 2) {
+                mfma_step(1, t - 1, carry, t, opens, 0);
+            } else {  // mode 3: the late half's first epoch has no previous stage to finish
+#pragma unroll
+                for (int q = 0; q < kHalfGroups; ++q) issue_quarter(t, opens, q);
+            }
+            uint32_t wx[4];
+            read_words(t, wx, carry);
+            mfma_step(0, t, wx, t, opens, kHalfGroups);
+        }
+    };
+    // the first epoch is peeled so that the late half's loop body is free of conditions around MFMAs
+    auto main_loop = [&](auto first_tag, auto mode_tag) {
+        epoch(std::integral_constant<int, 0>{}, first_tag, 0);
+        if (1 < stages) epoch(std::integral_constant<int, 1>{}, mode_tag, 1);
+        if (2 < stages) epoch(std::integral_constant<int, 2>{}, mode_tag, 2);
+        if (3 < stages) epoch(std::integral_constant<int, 3>{}, mode_tag, 3);
+        for (int t0 = 4; t0 < stages; t0 += 4) {
+            epoch(std::integral_constant<int, 0>{}, mode_tag, t0);
+            if (t0 + 1 < stages) epoch(std::integral_constant<int, 1>{}, mode_tag, t0 + 1);
+            if (t0 + 2 < stages) epoch(std::integral_constant<int, 2>{}, mode_tag, t0 + 2);
+            if (t0 + 3 < stages) epoch(std::integral_constant<int, 3>{}, mode_tag, t0 + 3);
+        }
+    };
+    if (!wave_active) main_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    else if (!late) main_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    else main_loop(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave_active) {
+        if (late) {
+            // the last stage's second step: its buffer is not a target of the clamped re-loads
+            const unsigned char *sb = smem + kLhsRing + ((stages - 1) & (kStaggerRing - 1)) * kRhsStage + lane * 16 +
+                                      kNB * kFragBytes;
+            v4i fa[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const uint32_t y = carry[rg] >> sh;
+                fa[rg][0] = (int)(y & 0x01010101u);
+                fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+                fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+                fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+            }
+#pragma unroll
+            for (int f = 0; f < kNB; ++f) {
+                const v4i fbv = *reinterpret_cast<const v4i *>(sb + f * kFragBytes);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    acc[rg][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fbv, acc[rg][f], 0, 0, 0);
+            }
+        }
+        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(512, 1) void binlimb_gemm16_stagger(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                                 int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm16_stagger_body<RING, true>(p, ell, mask, b, nt, mt, smem);
+    else gemm16_stagger_body<RING, false>(p, ell, mask, b, nt, mt, smem);
 }
 
 // Timing-only diagnostic builds of the kernel above (Fp, 4 waves): results are wrong by design.
@@ -1014,9 +1245,9 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
 #undef GSW_ABL
         return hipGetLastError();
     }
-    if (variant < 0 || variant > 7) return hipErrorInvalidValue;
+    if (variant < 0 || variant > 8) return hipErrorInvalidValue;
     if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
-    const int tile_rows = (variant == 1 || variant == 5 || variant == 7) ? 512 : 256;
+    const int tile_rows = (variant == 1 || variant == 5 || variant == 7 || variant == 8) ? 512 : 256;
     const int nt = col_tiles(a.out_cols);
     const int mt = (a.rows + tile_rows - 1) / tile_rows;
     const long units = (long)a.batch * nt;
@@ -1057,9 +1288,13 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
             if (fp) GSW_LAUNCH((binlimb_gemm16_rowblock<kRingFp, 4>), 256, rowblock_lds_bytes<4>());
             else GSW_LAUNCH((binlimb_gemm16_rowblock<kRingZpow2, 4>), 256, rowblock_lds_bytes<4>());
             break;
-        default:
+        case 7:
             if (fp) GSW_LAUNCH((binlimb_gemm16_rowblock<kRingFp, 8>), 512, rowblock_lds_bytes<8>());
             else GSW_LAUNCH((binlimb_gemm16_rowblock<kRingZpow2, 8>), 512, rowblock_lds_bytes<8>());
+            break;
+        default:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_stagger<kRingFp>), 512, stagger_lds_bytes());
+            else GSW_LAUNCH((binlimb_gemm16_stagger<kRingZpow2>), 512, stagger_lds_bytes());
             break;
     }
 #undef GSW_LAUNCH
