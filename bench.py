@@ -35,7 +35,7 @@ KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined
                 2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>",
                 4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>",
                 6: "binlimb_gemm16_rowblock<4 waves>", 7: "binlimb_gemm16_rowblock<8 waves>",
-                8: "binlimb_gemm16_stagger"}
+                8: "binlimb_gemm16_stagger", 9: "binlimb_gemm16_skew"}
 
 WORKLOADS = {
     # name: (ring, n, default batch)
@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
+    ap.add_argument("--diag-pool", choices=["uniform", "zero", "sparse"], default="uniform",
+                    help="diagnostic: operand data pattern (anything but uniform is not the benchmark)")
     ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..8 (default: chosen by shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU work for the baseline sample")
@@ -159,6 +161,11 @@ def main():
     _lib.check(L.gsw_fill_uniform(eng.handle, 0x6A5C0000 + 1, rank, 0, ring.max_u64(), 1, pool_t.data_ptr(),
                                   pool * ct))
     pool_t[:, :, n + 1:] = 0
+    if args.diag_pool == "zero":      # diagnostic only: how much of the kernel's time is clock (power), not cycles
+        pool_t.zero_()
+    elif args.diag_pool == "sparse":  # one bit set per element
+        pool_t.copy_(torch.ones_like(pool_t) << (pool_t & 7))
+        pool_t[:, :, n + 1:] = 0
     out_t = torch.empty((batch, big_n, ld), dtype=torch.int32, device=dev)
     digests = torch.zeros(batch, dtype=torch.int64, device=dev)
     lhs_idx = [(2 * b) % pool for b in range(batch)]
@@ -207,7 +214,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8 MFMA, int32 accumulate (exact), u32 ring elements",
-            "data": "synthetic",
+            "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
             "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
                                    f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
                        "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}"},

@@ -49,7 +49,7 @@ def _assert_equal(got, expect, what):
 # kernel variants: 0 = pipelined 256-row tile (default), 1 = pipelined 512-row tile, 2 = simple LDS-DMA,
 # 3 = simple register staging, 4/5 = pipelined on the 16x16x64 MFMA shape (256/512-row tile), 6/7 = the same with 64-byte left-operand loads.  n + 1 columns: 2, 4, 8 (a packed tile only), 11, 33/34/40 (full + packed
 # tail), 41 (full + unpacked tail), 72 (two full + packed tail of 8)
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9"])
 @pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 7), ("fp", 32), ("fp", 39),
                                           ("fp", 40), ("fp", 71), ("z30", 10), ("z31", 10), ("z32", 10),
                                           ("z32", 33), ("z8", 5)])

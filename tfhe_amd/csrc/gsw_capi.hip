@@ -212,14 +212,13 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_limit = (size_t)2 << 30;
-    // 16x16x64 MFMA with 64-byte left-operand loads: 256-row tiles, two workgroups per CU (6), or for
-    // large N the staggered 512-row tile (8), which halves the right-operand traffic per MFMA
-    ctx->gemm_variant = ctx->big_n >= 12288 ? 8 : 6;
+    // 16x16x64 MFMA, 256-row tiles, 64-byte left-operand loads, software-pipelined instruction stream
+    ctx->gemm_variant = 9;
     ctx->timing = false;
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
-    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 8) && !(ctx->gemm_variant >= 10 && ctx->gemm_variant < 138)) {
+    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 9) && !(ctx->gemm_variant >= 10 && ctx->gemm_variant < 138)) {
         delete ctx;
-        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..8");
+        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..9");
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);

@@ -894,6 +894,242 @@ __global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_rowblock(GemmArg
     else gemm16_rowblock_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
 }
 
+// ---- Skewed 256-row pipeline (full column tiles).
+//
+// Same tile, rings and loads as the row-block kernel above, but a wave's instruction stream is software
+// pipelined so that it never stops issuing MFMAs for its own bookkeeping:
+//  * the last MFMA group of stage t runs after the barrier that opens stage t + 1, covering the latency
+//    of the first right-operand fragment reads of that stage;
+//  * the left-operand words of stage t + 1 (a private ring: no barrier needed) are read, counted and
+//    expanded into int8 fragments between the MFMAs of stage t, and the step-1 fragments of a stage
+//    between the MFMAs of its step 0.
+// Two fragment sets (fa0 / fa1) alternate; the right-operand fragments keep two register groups.
+
+#ifndef GSW_SKEW_INTERLEAVE
+#define GSW_SKEW_INTERLEAVE 1
+#endif
+
+template <int RING>
+__device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
+                                                 unsigned char *smem) {
+    constexpr int WAVES = 4;
+    constexpr int kRows = 64 * WAVES;
+    constexpr int kLhsRing = 2 * WAVES * 4096;
+    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
+    constexpr int kNB = 8;
+    constexpr int kPieces = 2 * kNB;
+    constexpr int kRounds = kPieces / WAVES;  // 4: one per MFMA group
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
+
+    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
+    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const int stages = p.e4 / kStageElems;
+    const bool wave_active = mt * kRows + wave * 64 < p.rows;
+
+    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
+    const uint32_t *a_row[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
+        if (row > p.rows - 1) row = p.rows - 1;
+        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
+    }
+
+    v4i acc[4][kNB];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int f = 0; f < kNB; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
+    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    const int r16 = lane & 15;
+    const int sh = ((lane >> 4) & 1) * 4;
+    const int swz = (r16 >> 2) & 3;
+    const int word_pair = (lane >> 5) * 8;
+
+    auto issue_lhs_piece = [&](int super_stage, int rg) {
+        int st = super_stage * 4 + ld_j;
+        if (st > stages - 1) st = stages - 1;
+        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
+        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
+    };
+    auto issue_rhs_round = [&](int t, int buf, int j) {
+        if (t > stages - 1) t = stages - 1;
+        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
+        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
+        const int piece = (j * WAVES + wave) % kPieces;
+        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+    };
+    // portion q (0..3) of the loads of the stage-t epoch: right-operand round q of stage t + 2, and
+    // piece q of the next super-stage's left operand when t opens a super-stage
+    auto issue_portion = [&](int t, int buf, bool opens, int q) {
+        if (opens) issue_lhs_piece((t >> 2) + 1, q);
+        issue_rhs_round(t + 2, buf == 0 ? 2 : buf - 1, q);
+    };
+    auto read_words = [&](int t, uint32_t (&wx)[4], uint32_t (&wy)[4]) {
+        const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
+                                              (((t & 3) ^ swz) * 16) + word_pair);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const uint2 w = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
+            wx[rg] = w.x;
+            wy[rg] = w.y;
+        }
+    };
+    auto count_words = [&](const uint32_t (&wx)[4], const uint32_t (&wy)[4]) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) pop[rg] += __popc(wx[rg]) + __popc(wy[rg]);
+    };
+    // keeps the compiler from sinking a fragment set's expansion below this point
+    auto pin = [&](v4i (&fa)[4]) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) asm volatile("" : "+v"(fa[rg]));
+    };
+    auto expand = [&](v4i (&fa)[4], const uint32_t (&word)[4]) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const uint32_t y = word[rg] >> sh;
+            fa[rg][0] = (int)(y & 0x01010101u);
+            fa[rg][1] = (int)((y >> 1) & 0x01010101u);
+            fa[rg][2] = (int)((y >> 2) & 0x01010101u);
+            fa[rg][3] = (int)((y >> 3) & 0x01010101u);
+        }
+    };
+    auto read_frags = [&](v4i (&fb)[4], int buf, int grp) {
+        const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16 + grp * 4 * kFragBytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
+    };
+    auto mfma_group = [&](const v4i (&fa)[4], const v4i (&fb)[4], int f0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                acc[rg][f0 + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[j], acc[rg][f0 + j], 0, 0, 0);
+        }
+    };
+    // 16 MFMAs with V vector ALU instructions after each of them (scheduler directive, no code)
+    auto interleave = [&](auto valu_tag) {
+#if GSW_SKEW_INTERLEAVE
+        constexpr int V = decltype(valu_tag)::value;
+#define GSW_SGB1                                       \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   \
+    __builtin_amdgcn_sched_group_barrier(0x2, V, 0);
+#define GSW_SGB4 GSW_SGB1 GSW_SGB1 GSW_SGB1 GSW_SGB1
+        GSW_SGB4 GSW_SGB4 GSW_SGB4 GSW_SGB4
+#undef GSW_SGB4
+#undef GSW_SGB1
+#endif
+    };
+
+    // prologue: left operand of super-stage 0, right operand of stages 0 and 1
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) issue_rhs_round(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, 1, j);
+
+    v4i fa0[4], fa1[4], fbA[4], fbB[4];
+    uint32_t wx[4] = {0u, 0u, 0u, 0u}, wy[4] = {0u, 0u, 0u, 0u};  // the current stage's words (wx: for counting)
+    int buf = 0;
+
+    auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t) {
+        constexpr int kSlot = decltype(slot_tag)::value;
+        constexpr bool kFirst = decltype(first_tag)::value;
+        constexpr bool kActive = decltype(active_tag)::value;
+        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
+        const bool opens = kSlot == 0;
+        if constexpr (!kActive) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_portion(t, buf, opens, q);
+        } else {
+            if constexpr (kFirst) {
+                read_words(t, wx, wy);
+                count_words(wx, wy);
+                expand(fa0, wx);
+            }
+            // phase 0: first fragments of this stage; the previous stage's last group covers their
+            // latency, and this stage's words are counted between its MFMAs
+            read_frags(fbA, buf, 0);
+            issue_portion(t, buf, opens, 0);
+            if constexpr (!kFirst) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(fa1, fbB, 4);
+                count_words(wx, wy);
+                interleave(std::integral_constant<int, 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 1: step 0, fragments 0..3; the step-1 fragments of this stage are expanded meanwhile
+            read_frags(fbB, buf, 1);
+            issue_portion(t, buf, opens, 1);
+            mfma_group(fa0, fbA, 0);
+            expand(fa1, wy);
+            pin(fa1);
+            interleave(std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2: step 0, fragments 4..7; the next stage's left-operand words are fetched
+            read_frags(fbA, buf, 2);
+            issue_portion(t, buf, opens, 2);
+            mfma_group(fa0, fbB, 4);
+            uint32_t nx[4], ny[4];
+            read_words(t + 1, nx, ny);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: step 1, fragments 0..3; the next stage's step-0 fragments are expanded
+            read_frags(fbB, buf, 3);
+            issue_portion(t, buf, opens, 3);
+            mfma_group(fa1, fbA, 0);
+            expand(fa0, nx);
+            pin(fa0);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                wx[rg] = nx[rg];
+                wy[rg] = ny[rg];
+            }
+            interleave(std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    };
+    auto main_loop = [&](auto active_tag) {
+        stage(std::integral_constant<int, 0>{}, std::true_type{}, active_tag, 0);
+        if (1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, 1);
+        if (2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, 2);
+        if (3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, 3);
+        for (int t0 = 4; t0 < stages; t0 += 4) {
+            stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, t0);
+            if (t0 + 1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, t0 + 1);
+            if (t0 + 2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, t0 + 2);
+            if (t0 + 3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, t0 + 3);
+        }
+    };
+    if (wave_active) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave_active) {
+        mfma_group(fa1, fbB, 4);  // the last stage's deferred group
+        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
+        gemm16_epilogue<RING, false>(p, c, kRows, acc, pop);
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                              int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, 4, true>(p, ell, mask, b, nt, mt, smem);
+    else gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
+}
+
 // ---- Staggered 512-row tile: 8 waves, one workgroup per CU.
 //
 // Waves w and w + 4 share a SIMD.  Between two barriers the early half (waves 0..3) runs both MFMA
@@ -1245,7 +1481,7 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
 #undef GSW_ABL
         return hipGetLastError();
     }
-    if (variant < 0 || variant > 8) return hipErrorInvalidValue;
+    if (variant < 0 || variant > 9) return hipErrorInvalidValue;
     if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
     const int tile_rows = (variant == 1 || variant == 5 || variant == 7 || variant == 8) ? 512 : 256;
     const int nt = col_tiles(a.out_cols);
@@ -1292,9 +1528,13 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
             if (fp) GSW_LAUNCH((binlimb_gemm16_rowblock<kRingFp, 8>), 512, rowblock_lds_bytes<8>());
             else GSW_LAUNCH((binlimb_gemm16_rowblock<kRingZpow2, 8>), 512, rowblock_lds_bytes<8>());
             break;
-        default:
+        case 8:
             if (fp) GSW_LAUNCH((binlimb_gemm16_stagger<kRingFp>), 512, stagger_lds_bytes());
             else GSW_LAUNCH((binlimb_gemm16_stagger<kRingZpow2>), 512, stagger_lds_bytes());
+            break;
+        default:
+            if (fp) GSW_LAUNCH((binlimb_gemm16_skew<kRingFp>), 256, rowblock_lds_bytes<4>());
+            else GSW_LAUNCH((binlimb_gemm16_skew<kRingZpow2>), 256, rowblock_lds_bytes<4>());
             break;
     }
 #undef GSW_LAUNCH
