@@ -347,11 +347,13 @@ class GSW:
         sk = self.make_sk(t)
         return sk, self.make_pk(rand_b.reshape(self.m, self.n), err, t)
 
-    def encrypt_batch(self, pk: PublicKey, messages: Sequence[int], rbits=None) -> Ciphertext:
+    def encrypt_batch(self, pk: PublicKey, messages: Sequence[int], rbits=None, out: Optional[Ciphertext] = None,
+                      slot: int = 0) -> Ciphertext:
         """Batched src/gsw/gsw_impl.rs:27-42 in compact form: R * pk_matrix + message * G.
 
         rbits: optional (batch, N, m) 0/1 bytes standing for rnd_dmatrix(N, m, 0, 1); when absent the
-        seeded device generator draws them.
+        seeded device generator draws them.  out / slot: write the ciphertexts into entries slot, slot + 1, ..
+        of an existing batch (a pool for eval_circuit) instead of a new one.
         """
         eng, L = self.engine, _lib.lib()
         if pk.prepared is None:
@@ -367,9 +369,14 @@ class GSW:
                 check(L.gsw_pack_rbits(eng.handle, rbits[b].ctypes.data, d_r.ptr + 4 * eng.rbits_elems * b))
         d_m = eng.alloc_u32(batch)
         d_m.upload(msgs)
-        ct = Ciphertext(eng, batch)
-        check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, ct.ptr, ct.stride,
-                                  batch))
+        if out is None:
+            ct, dst = Ciphertext(eng, batch), None
+        else:
+            if slot < 0 or slot + batch > out.batch:
+                raise ValueError(f"entries {slot}..{slot + batch - 1} do not fit a batch of {out.batch}")
+            ct, dst = out, out.entry_ptr(slot)
+        check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr,
+                                  ct.ptr if dst is None else dst, ct.stride, batch))
         eng.sync()
         return ct
 
@@ -377,13 +384,18 @@ class GSW:
         """src/gsw/gsw_impl.rs:27-42."""
         return self.encrypt_batch(pk, [message], None if rbits is None else np.asarray(rbits)[None])
 
-    def decrypt_batch(self, sk: SecretKey, ct: Ciphertext, raw: bool = False):
+    def decrypt_batch(self, sk: SecretKey, ct: Ciphertext, raw: bool = False, slot: int = 0,
+                      count: Optional[int] = None):
+        """Batched src/gsw/gsw_impl.rs:48-52; slot / count select a range of entries (default: all)."""
         eng = self.engine
-        bits = np.empty(ct.batch, dtype=np.uint32)
-        rawv = np.empty(ct.batch, dtype=np.uint32)
+        count = ct.batch - slot if count is None else count
+        if slot < 0 or count < 0 or slot + count > ct.batch:
+            raise ValueError(f"entries {slot}..{slot + count - 1} are outside a batch of {ct.batch}")
+        bits = np.empty(count, dtype=np.uint32)
+        rawv = np.empty(count, dtype=np.uint32)
         s = np.ascontiguousarray(sk.s, dtype=np.uint32)
-        check(_lib.lib().gsw_decrypt_batch(eng.handle, s.ctypes.data, ct.ptr, ct.stride, ct.batch, bits.ctypes.data,
-                                           rawv.ctypes.data))
+        check(_lib.lib().gsw_decrypt_batch(eng.handle, s.ctypes.data, ct.entry_ptr(slot), ct.stride, count,
+                                           bits.ctypes.data, rawv.ctypes.data))
         return (bits, rawv) if raw else bits
 
     def decrypt(self, sk: SecretKey, ct: Ciphertext) -> int:
