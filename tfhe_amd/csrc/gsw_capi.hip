@@ -720,6 +720,8 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
         return mul_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags, d_digests);
     }
     size_t pipe_chunk = (size_t)ctx->overlap_chunk;
+    // shorter batches (one level of a circuit) still get four chunks to overlap, down to 32 products
+    if (pipe_chunk && (size_t)batch < 4 * pipe_chunk) pipe_chunk = (size_t)batch / 4 > 32 ? (size_t)batch / 4 : 32;
     if (pipe_chunk > ctx->ws_limit / (2 * prep)) pipe_chunk = ctx->ws_limit / (2 * prep);
     if (pipe_chunk >= 1 && (size_t)batch > pipe_chunk) {
         // Two-stage pipeline over chunks: the (HBM-bound) preparation of chunk k+1 runs on the auxiliary
