@@ -21,6 +21,8 @@ def _rings(oracle, tfhe_amd):
         "z31": (oracle.zpow2(31), tfhe_amd.Zpow2(31)),
         "z32": (oracle.zpow2(32), tfhe_amd.Zpow2(32)),
         "z8": (oracle.zpow2(8), tfhe_amd.Zpow2(8)),
+        "z2": (oracle.zpow2(2), tfhe_amd.Zpow2(2)),
+        "z1": (oracle.zpow2(1), tfhe_amd.Zpow2(1)),
     }
 
 
@@ -52,7 +54,7 @@ def _assert_equal(got, expect, what):
 @pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9"])
 @pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 7), ("fp", 32), ("fp", 39),
                                           ("fp", 40), ("fp", 71), ("z30", 10), ("z31", 10), ("z32", 10),
-                                          ("z32", 33), ("z8", 5)])
+                                          ("z32", 33), ("z8", 5), ("z2", 9), ("z1", 40)])
 def test_mul_gadget_random_operands(oracle, tfhe_amd, ring_name, n, variant):
     """Pc = BitDecomp(C1c) * C2c on uniform random operands (every bit pattern exercised)."""
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
@@ -111,6 +113,34 @@ def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
     with pytest.raises(tfhe_amd.GswError):
         _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr + 4, d1.stride, d2.ptr, 0, out.ptr, out.stride,
                                                    1, 0))
+
+
+def test_empty_batches_and_ragged_public_keys(oracle, tfhe_amd):
+    """batch = 0 is a no-op everywhere; m need not be a multiple of ell (the last word of a row of
+    encryption bits is partly used) nor equal n * ell."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n, m = 5, 5 * 31 + 17
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=8)
+    eng = gsw.engine
+    ct = tfhe_amd.Ciphertext(eng, 1)
+    _lib.check(L.gsw_mul_gadget_batch(eng.handle, ct.ptr, ct.stride, ct.ptr, ct.stride, ct.ptr, ct.stride, 0, 0))
+    _lib.check(L.gsw_prepare_rhs(eng.handle, ct.ptr, ct.stride, ct.ptr, 0))
+    gsw.eval_circuit(ct, [])
+    sk, pk = gsw.keygen()
+    assert gsw.decrypt_batch(sk, ct, count=0).size == 0
+    assert pk.pk_matrix.shape == (m, n + 1)
+    og = oracle.GSW(ring_o, n, m)
+    rng = np.random.default_rng(3)
+    rbits = rng.integers(0, 2, size=(2, ring_o.big_n(n), m), dtype=np.uint8)
+    got = gsw.encrypt_batch(pk, [1, 0], rbits=rbits)
+    opk = oracle.PublicKey(pk.b, pk.pk_matrix)
+    for b, msg in enumerate([1, 0]):
+        _assert_equal(got.to_compact()[b], og.encrypt_compact(opk, msg, rbits[b]), f"ragged m, message {msg}")
+    assert gsw.decrypt_batch(sk, got).tolist() == [1, 0]
+    assert gsw.decrypt_batch(sk, gsw.encrypt_batch(pk, [0, 1, 1])).tolist() == [0, 1, 1]  # device-drawn bits
 
 
 def test_workspace_chunking(oracle, tfhe_amd):
