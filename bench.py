@@ -134,7 +134,12 @@ def cpu_baseline(engine, ring, n, pool_t, lhs_idx, rhs_idx, out_t, seconds: floa
 
 def main():
     args = parse_args()
-    rank, local_rank, world = gdist.init()
+    # GSW_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo, to exercise the multi-rank control flow on a
+    # one-GPU box (RCCL refuses two ranks on one device); its numbers are not a measurement
+    rehearsal = os.environ.get("GSW_BENCH_REHEARSAL") == "1"
+    rank, local_rank, world = gdist.init("gloo" if rehearsal else None)
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -217,7 +222,7 @@ def main():
             "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
             "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
                                    f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
-                       "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}"},
+                       "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),

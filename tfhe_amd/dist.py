@@ -59,6 +59,8 @@ def gather_to_root(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]
     if not dist.is_initialized():
         return [t]
     world = dist.get_world_size()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        t = t.cpu()  # gloo gathers host tensors only (CPU tests, single-GPU rehearsals of the multi-rank path)
     if dist.get_rank() == dst:
         out = [torch.empty_like(t) for _ in range(world)]
         dist.gather(t, gather_list=out, dst=dst)
