@@ -228,7 +228,7 @@ def main():
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),
                 "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
                 "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
-                "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} (wrong results by design)"),
+                "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} of a -DGSW_DIAGNOSTIC_BUILDS library (wrong results by design)"),
                 "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
                 "products_per_launch": mults_per_launch,
                 "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),

@@ -246,6 +246,12 @@ def test_errors_mirror_the_reference_panics(tfhe_amd):
         g.make_pk(np.zeros((62, 2)), np.zeros(61), np.zeros(2))
     with pytest.raises(tfhe_amd.GswError):
         tfhe_amd.Engine(tfhe_amd.Zpow2(40), 2, 80)
+    os.environ["GSW_GEMM_VARIANT"] = "12"  # a timing-only diagnostic build: absent from the shipped library
+    try:
+        with pytest.raises(tfhe_amd.GswError, match="GSW_GEMM_VARIANT"):
+            tfhe_amd.Engine(tfhe_amd.Fp(), 2, 62)
+    finally:
+        os.environ.pop("GSW_GEMM_VARIANT", None)
 
 
 @pytest.mark.parametrize("ring_name", ["fp", "z30"])

@@ -1351,7 +1351,9 @@ __global__ __launch_bounds__(512, 1) void binlimb_gemm16_stagger(GemmArgs p, int
     else gemm16_stagger_body<RING, false>(p, ell, mask, b, nt, mt, smem);
 }
 
-// Timing-only diagnostic builds of the kernel above (Fp, 4 waves): results are wrong by design.
+// Timing-only diagnostic builds of the 16x16x64 pipeline (Fp, 4 waves): results are WRONG by design, so
+// they exist only in libraries compiled with -DGSW_DIAGNOSTIC_BUILDS (never the shipped one).
+#ifdef GSW_DIAGNOSTIC_BUILDS
 template <int ABL>
 __global__ __launch_bounds__(256, 2) void binlimb_gemm16_ablate(GemmArgs p, int ell, uint32_t mask, int nt_count,
                                                                  int mt_count) {
@@ -1361,6 +1363,7 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_ablate(GemmArgs p, int 
     if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<kRingFp, 4, true, ABL>(p, ell, mask, b, nt, mt, smem);
     else gemm16_pipelined_body<kRingFp, 4, false, ABL>(p, ell, mask, b, nt, mt, smem);
 }
+#endif  // GSW_DIAGNOSTIC_BUILDS
 
 // Counter calibration: streams `bytes` (a multiple of 64 KiB) once through the same LDS-DMA instruction
 // the contraction uses, 1 KiB per wave instruction (mode 0) or 16 rows x 64 B at `pitch` bytes (mode 1),
@@ -1464,6 +1467,7 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
 
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream) {
     if (a.batch <= 0) return hipSuccess;
+#ifdef GSW_DIAGNOSTIC_BUILDS
     if (variant >= 10 && variant < 138 && ring.kind == kRingFp) {
         // diagnostic builds: variant = 10 + ABL
         const int nt = col_tiles(a.out_cols), mt = (a.rows + 255) / 256;
@@ -1481,6 +1485,7 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
 #undef GSW_ABL
         return hipGetLastError();
     }
+#endif
     if (variant < 0 || variant > 9) return hipErrorInvalidValue;
     if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
     const int tile_rows = (variant == 1 || variant == 5 || variant == 7 || variant == 8) ? 512 : 256;
