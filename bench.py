@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
+    ap.add_argument("--gather", choices=["digest", "full"], default="digest",
+                    help="what rank 0 collects each step: 64-bit digests of every product plus one sampled product "
+                         "per rank (default), or every product, drained to pinned host memory in chunks (bounded "
+                         "by the root's xGMI / PCIe ingress, not by the kernels)")
     ap.add_argument("--diag-pool", choices=["uniform", "zero", "sparse"], default="uniform",
                     help="diagnostic: operand data pattern (anything but uniform is not the benchmark)")
     ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..8 (default: chosen by shape)")
@@ -179,6 +183,10 @@ def main():
     # strided call; a smaller pool wraps around in `pool / 2`-sized calls
     per_call = min(batch, pool // 2)
 
+    drain = None
+    if args.gather == "full":
+        drain = gdist.ResultDrain((big_n, ld), torch.int32, world, rank, batch, chunk=32, device=dev)
+
     def step():
         for b0 in range(0, batch, per_call):
             cur = min(per_call, batch - b0)
@@ -186,7 +194,9 @@ def main():
                                                      pool_t.data_ptr() + 4 * ct, 2 * ct,
                                                      out_t.data_ptr() + 4 * ct * b0, ct, cur, 0,
                                                      digests.data_ptr() + 8 * b0))
-        if world > 1:
+        if drain is not None:
+            drain.run(out_t)  # every product of every rank to rank 0's host memory
+        elif world > 1:
             # the only exchange step: digests of every product + one sampled product per rank to rank 0
             gdist.gather_to_root(digests)
             gdist.gather_to_root(out_t[0])
@@ -222,7 +232,7 @@ def main():
             "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
             "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
                                    f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
-                       "batch_per_gpu": batch, "pool": pool, "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
+                       "batch_per_gpu": batch, "pool": pool, "gather": args.gather, "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),

@@ -79,3 +79,33 @@ def test_two_rank_gather_matches_single_process(tmp_path, oracle):
     assert got["digests"].tolist() == [oracle.digest(want[b]) for b in range(batch)]
     lo1, _ = (3, 5)  # rank 1 of 2 owns entries [3, 5) of 5
     assert np.array_equal(got["sample1"].astype(np.uint32), want[lo1])
+
+
+def _drain_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from tfhe_amd import dist as gdist
+
+    gdist.init(backend="gloo")
+    entries, shape = 7, (5, 3)
+    mine = (torch.arange(entries * 15, dtype=torch.int32).reshape(entries, *shape) + 1000 * rank)
+    drain = gdist.ResultDrain(shape, torch.int32, world, rank, entries, chunk=3, device="cpu")  # 3 + 3 + 1 (padded)
+    for _ in range(2):  # reusable: the second batch overwrites the first
+        host = drain.run(mine)
+    if rank == 0:
+        np.save(out_path, host.numpy())
+    else:
+        assert host is None
+    gdist.barrier()
+    gdist.shutdown()
+
+
+def test_result_drain_gathers_every_entry_in_chunks(tmp_path):
+    world = 2
+    out_path = str(tmp_path / "drain.npy")
+    mp.spawn(_drain_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    base = np.arange(7 * 15, dtype=np.int32).reshape(7, 5, 3)
+    assert got.shape == (2, 7, 5, 3)
+    assert np.array_equal(got[0], base) and np.array_equal(got[1], base + 1000)

@@ -69,6 +69,78 @@ def gather_to_root(t: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]
     return None
 
 
+class ResultDrain:
+    """Gathers every rank's batch of results to host memory on rank `dst`, in chunks.
+
+    A whole batch does not fit the root GPU next to its own work (16 384 products of n = 512 are 534 GB),
+    so the ranks send `chunk` entries at a time: one `gather` per chunk into one of two receive buffers on
+    the root (RCCL: every peer sends over its own xGMI link), while the previous chunk drains from the
+    other buffer to pinned host memory on a side stream.  Root ingress bounds the rate (7 links), so this
+    is an exchange step to run beside compute on a dedicated stream, never inside a kernel-bound loop.
+    """
+
+    def __init__(self, entry_shape, dtype, world: int, rank: int, entries: int, chunk: int, device, dst: int = 0):
+        self.world, self.rank, self.dst, self.entries = world, rank, dst, entries
+        self.chunk = max(1, min(chunk, entries)) if entries else 1
+        self.device = torch.device(device)
+        self.root = rank == dst
+        self.cuda = self.device.type == "cuda"
+        shape = (self.chunk,) + tuple(entry_shape)
+        if self.root:
+            self.recv = [[torch.empty(shape, dtype=dtype, device=self.device) for _ in range(world)] for _ in range(2)]
+            self.host = torch.empty((world, entries) + tuple(entry_shape), dtype=dtype, pin_memory=self.cuda)
+            self.side = torch.cuda.Stream(self.device) if self.cuda else None
+            self.done = [None, None]
+
+    def run(self, results: torch.Tensor) -> Optional[torch.Tensor]:
+        """results: this rank's (entries, *entry_shape) tensor on `device`.  Returns, on the root, the
+        (world, entries, *entry_shape) host tensor; None elsewhere."""
+        if results.shape[0] != self.entries:
+            raise ValueError(f"expected {self.entries} entries, got {results.shape[0]}")
+        for k, lo in enumerate(range(0, self.entries, self.chunk)):
+            hi = min(lo + self.chunk, self.entries)
+            part = results[lo:hi]
+            if hi - lo < self.chunk:  # equal shapes on every rank and every call: pad the last chunk
+                pad = torch.zeros((self.chunk,) + tuple(results.shape[1:]), dtype=results.dtype, device=results.device)
+                pad[: hi - lo] = part
+                part = pad
+            part = part.contiguous()
+            if dist.is_initialized() and part.is_cuda and dist.get_backend() == "gloo":
+                part = part.cpu()
+            if not self.root:
+                dist.gather(part, gather_list=None, dst=self.dst)
+                continue
+            bufs = self.recv[k & 1]
+            if self.done[k & 1] is not None:
+                self.done[k & 1].synchronize()  # the drain of chunk k - 2 has left this buffer
+            if dist.is_initialized():
+                if part.device != bufs[0].device:
+                    staged = [torch.empty_like(part) for _ in range(self.world)]
+                    dist.gather(part, gather_list=staged, dst=self.dst)
+                    for b, s_ in zip(bufs, staged):
+                        b.copy_(s_)
+                else:
+                    dist.gather(part, gather_list=bufs, dst=self.dst)
+            else:
+                bufs[0].copy_(part)
+            if self.cuda:
+                self.side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.side):
+                    for r in range(self.world):
+                        self.host[r, lo:hi].copy_(bufs[r][: hi - lo], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                self.done[k & 1] = ev
+            else:
+                for r in range(self.world):
+                    self.host[r, lo:hi].copy_(bufs[r][: hi - lo])
+        if not self.root:
+            return None
+        if self.cuda:
+            self.side.synchronize()
+        return self.host
+
+
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
