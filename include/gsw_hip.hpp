@@ -250,6 +250,60 @@ class GSW {
                                gates.size()));
     }
 
+    // ---- wire format (layout in gsw_hip.h; the reference has no serialisation) ----
+    std::vector<uint8_t> to_wire(const CompactCiphertext &c) {
+        std::vector<uint8_t> out(gsw_wire_bytes(ctx_, GSW_WIRE_CIPHERTEXT, c.batch));
+        check(gsw_wire_write_compact(ctx_, c.buf.u32(), gsw_ctx_compact_elems(ctx_), c.batch, out.data(), out.size()));
+        return out;
+    }
+    CompactCiphertext ciphertext_from_wire(const std::vector<uint8_t> &wire) {
+        int count = 0;
+        check(gsw_wire_read_compact(ctx_, wire.data(), wire.size(), nullptr, 0, 0, &count));
+        const size_t elems = gsw_ctx_compact_elems(ctx_);
+        CompactCiphertext out{DeviceBuffer(ctx_, elems * 4 * (size_t)(count > 0 ? count : 1)), count};
+        check(gsw_wire_read_compact(ctx_, wire.data(), wire.size(), out.buf.u32(), elems, count, &count));
+        return out;
+    }
+    std::vector<uint8_t> to_wire(const GswPk &pk) {
+        std::vector<uint8_t> out(gsw_wire_bytes(ctx_, GSW_WIRE_PUBLIC_KEY, 1));
+        std::vector<uint32_t> rm = pk.pk_matrix.row_major();
+        check(gsw_wire_write_host(ctx_, GSW_WIRE_PUBLIC_KEY, rm.data(), out.data(), out.size()));
+        return out;
+    }
+    GswPk pk_from_wire(const std::vector<uint8_t> &wire) {
+        std::vector<uint32_t> rm((size_t)m_ * (n_ + 1));
+        check(gsw_wire_read_host(ctx_, GSW_WIRE_PUBLIC_KEY, wire.data(), wire.size(), rm.data()));
+        GswPk pk;
+        pk.pk_matrix = DMatrix::from_row_major(m_, n_ + 1, rm);
+        pk.b.resize(m_);
+        for (int i = 0; i < m_; ++i) pk.b[i] = rm[(size_t)i * (n_ + 1)];
+        return pk;
+    }
+    std::vector<uint8_t> to_wire(const GswSk &sk) {
+        std::vector<uint8_t> out(gsw_wire_bytes(ctx_, GSW_WIRE_SECRET_KEY, 1));
+        check(gsw_wire_write_host(ctx_, GSW_WIRE_SECRET_KEY, sk.t.data(), out.data(), out.size()));
+        return out;
+    }
+    GswSk sk_from_wire(const std::vector<uint8_t> &wire) {
+        std::vector<uint32_t> t((size_t)n_);
+        check(gsw_wire_read_host(ctx_, GSW_WIRE_SECRET_KEY, wire.data(), wire.size(), t.data()));
+        return make_sk(t);
+    }
+
+    // ---- threshold hooks: additive shares of sk.s (tfhe_gsw_fp.rs:14-18), part_dec (a todo!() at :27-29) ----
+    uint32_t part_dec(const std::vector<uint32_t> &share, const CompactCiphertext &c, int b = 0) {
+        if ((int)share.size() != n_ + 1) throw std::runtime_error("a share of sk.s has n + 1 entries");
+        uint32_t partial = 0;
+        check(gsw_partial_decrypt_batch(ctx_, share.data(), c.buf.u32() + (size_t)b * gsw_ctx_compact_elems(ctx_), 0, 1,
+                                        &partial));
+        return partial;
+    }
+    uint32_t combine_partials(const std::vector<uint32_t> &partials) {
+        uint32_t bit = 0;
+        check(gsw_combine_partials(ctx_, partials.data(), (int)partials.size(), 1, &bit));
+        return bit;
+    }
+
     // ---- conversions between the reference's dense form and the compact form ----
     // BitDecomp^-1 (linear) of a dense matrix, uploaded as a compact ciphertext
     CompactCiphertext flatten_to_compact(const DMatrix &c) {

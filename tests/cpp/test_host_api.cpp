@@ -136,6 +136,38 @@ static void nand_gates_over_a_pool() {
     EXPECT(throws_with([&] { fhe.eval_circuit(pool, {{GSW_GATE_MULT, 0, 1, 1}}); }, "own operand"));
 }
 
+static void wire_round_trip_and_threshold_hooks() {
+    GSW<Fp> alice(10, 310, Sampler::DiscrGaussian, 9), bob(10, 310, Sampler::DiscrGaussian, 10);
+    auto keys = alice.keygen();
+    // the public key travels to a second context, which encrypts and multiplies; the product travels back
+    GswPk pk_b = bob.pk_from_wire(alice.to_wire(keys.second));
+    EXPECT(pk_b.pk_matrix == keys.second.pk_matrix);
+    CompactCiphertext one = bob.encrypt_compact(pk_b, 1), zero = bob.encrypt_compact(pk_b, 0);
+    CompactCiphertext back = alice.ciphertext_from_wire(bob.to_wire(bob.nand(one, zero)));
+    GswSk sk = alice.sk_from_wire(alice.to_wire(keys.first));
+    EXPECT(sk.s == keys.first.s && sk.v == keys.first.v);
+    EXPECT(alice.decrypt(sk, back) == 1);
+    // a flipped payload byte is caught by the digest
+    std::vector<uint8_t> wire = bob.to_wire(one);
+    wire[40] ^= 1;
+    EXPECT(throws_with([&] { alice.ciphertext_from_wire(wire); }, "digest"));
+    // three additive shares of s: the partial decryptions recombine to the plain decryption
+    std::vector<std::vector<uint32_t>> shares(3, std::vector<uint32_t>(sk.s.size()));
+    uint64_t x = 88172645463325252ull;
+    for (size_t j = 0; j < sk.s.size(); ++j) {
+        uint64_t sum = 0;
+        for (int p = 0; p < 2; ++p) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            shares[p][j] = (uint32_t)(x % Fp::P);
+            sum += shares[p][j];
+        }
+        shares[2][j] = (uint32_t)(((uint64_t)sk.s[j] + 2 * Fp::P - sum % Fp::P) % Fp::P);
+    }
+    std::vector<uint32_t> partials;
+    for (auto &sh : shares) partials.push_back(alice.part_dec(sh, back));
+    EXPECT(alice.combine_partials(partials) == 1);
+}
+
 static void panics_of_the_reference() {
     GSW<Fp> fhe(2, 62);
     EXPECT(throws_with([&] { fhe.mult(DMatrix(3, 3), DMatrix(4, 4)); }, "different sizes"));       // gsw_impl.rs:105-106
@@ -160,6 +192,7 @@ int main() {
         mult_nand_add_on_reference_format();
         gadget_path_equals_dense_product_of_flattened_operands();
         nand_gates_over_a_pool();
+        wire_round_trip_and_threshold_hooks();
         panics_of_the_reference();
     } catch (const std::exception &e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());
