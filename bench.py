@@ -228,7 +228,7 @@ def main():
             "metric": "GSW ciphertext mults/sec (node)", "value": total_mults / elapsed, "unit": "mults/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int8 MFMA, int32 accumulate (exact), u32 ring elements",
+            "vs_baseline": None, "dtype": "int8",  # int8 MFMA, exact int32 accumulation, u32 ring elements
             "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
             "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
                                    f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
@@ -237,7 +237,8 @@ def main():
                 "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                 "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),
                 "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
-                "op_kind": "int8 multiply-accumulate counted as 2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
+                "op_kind": "int8 MFMA multiply-accumulate (exact int32 accumulation, u32 ring elements) counted as "
+                           "2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
                 "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} of a -DGSW_DIAGNOSTIC_BUILDS library (wrong results by design)"),
                 "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
                 "products_per_launch": mults_per_launch,
