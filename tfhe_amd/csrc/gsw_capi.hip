@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,11 @@ int fail(int code, const char *fmt, ...) {
     g_last_error = buf;
     return code;
 }
+
+// No exception may cross the C ABI: the entry points that allocate host memory are function-try-blocks.
+#define GSW_CATCH                                                                                     \
+    catch (const std::bad_alloc &) { return fail(GSW_E_NOMEM, "host allocation failed"); }            \
+    catch (const std::exception &e) { return fail(GSW_E_INVALID, "unexpected exception: %s", e.what()); }
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -108,7 +115,12 @@ struct ScopedTimer {
     ~ScopedTimer() {
         if (on) {
             hipEventRecord(t.stop, stream);
-            ctx->timed[which].push_back(t);
+            try {
+                ctx->timed[which].push_back(t);
+            } catch (...) {  // out of host memory: this launch goes untimed
+                (void)hipEventDestroy(t.start);
+                (void)hipEventDestroy(t.stop);
+            }
         }
     }
 };
@@ -171,7 +183,7 @@ extern "C" {
 const char *gsw_last_error(void) { return g_last_error.c_str(); }
 const char *gsw_version(void) { return "gsw-mi355x 0.1 (gfx950)"; }
 
-int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int device) {
+int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int device) try {
     if (!out) return fail(GSW_E_INVALID, "null output pointer");
     *out = nullptr;
     gswk::RingDesc ring{};
@@ -248,6 +260,7 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     *out = ctx;
     return GSW_OK;
 }
+GSW_CATCH
 
 void gsw_ctx_destroy(gsw_ctx *ctx) {
     if (!ctx) return;
@@ -326,7 +339,7 @@ int gsw_ctx_reset_timing(gsw_ctx *ctx) {
     return GSW_OK;
 }
 
-int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launches) {
+int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launches) try {
     if (!ctx || which < 0 || which > 1 || !total_ms || !launches) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -341,6 +354,7 @@ int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launche
     *launches = (long)ctx->timed[which].size();
     return GSW_OK;
 }
+GSW_CATCH
 
 // ---- device memory helpers ----
 
@@ -789,7 +803,7 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
 // ---- gate lists over a pool of resident ciphertexts ----
 
 int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
-                     size_t n_gates) {
+                     size_t n_gates) try {
     if (!ctx) return fail(GSW_E_INVALID, "null context");
     if (n_gates == 0) return GSW_OK;
     if (!d_pool || !h_gates) return fail(GSW_E_INVALID, "null operand");
@@ -892,10 +906,11 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
     }
     return GSW_OK;
 }
+GSW_CATCH
 
 // ---- encrypt ----
 
-int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepared) {
+int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepared) try {
     if (!ctx || !h_pk_matrix || !d_pk_prepared || !aligned16(d_pk_prepared)) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     // stage pk_matrix (m x (n+1), pk.rs:28-38) on the device with the padded leading dimension
@@ -928,8 +943,9 @@ int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepare
     HIP_TRY(e);
     return rc;
 }
+GSW_CATCH
 
-int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits, uint32_t *d_rbits) {
+int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits, uint32_t *d_rbits) try {
     if (!ctx || !h_bits || !d_rbits) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     const int ell = ctx->ring.ell, words = ctx->words;
@@ -946,6 +962,7 @@ int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits, uint32_t *d_rbits) {
         }
     return gsw_memcpy_h2d(ctx, d_rbits, packed.data(), packed.size() * 4);
 }
+GSW_CATCH
 
 int gsw_random_rbits(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_rbits, int batch) {
     if (!ctx || !d_rbits || batch < 0) return fail(GSW_E_INVALID, "bad argument");
@@ -1010,7 +1027,7 @@ static uint32_t is_zero_one(const gswk::RingDesc &ring, uint32_t x) {
 }
 
 int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
-                      uint32_t *h_bits_out, uint32_t *h_raw_out) {
+                      uint32_t *h_bits_out, uint32_t *h_raw_out) try {
     if (!ctx || !h_s || !d_cc || !h_bits_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (batch == 0) return GSW_OK;
     if (int rc = use_device(ctx)) return rc;
@@ -1022,9 +1039,10 @@ int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, s
     }
     return GSW_OK;
 }
+GSW_CATCH
 
 int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,
-                         uint32_t *h_messages_out) {
+                         uint32_t *h_messages_out) try {
     if (!ctx || !h_s || !d_cc || !h_messages_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (ctx->ring.kind == gswk::kRingFp) return fail(GSW_E_UNSUPPORTED, "Only supported for pow2 rings!");  // gsw_impl.rs:69
     if (batch == 0) return GSW_OK;
@@ -1046,9 +1064,10 @@ int gsw_mp_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc
     }
     return GSW_OK;
 }
+GSW_CATCH
 
 int gsw_partial_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_share, const uint32_t *d_cc, size_t stride, int batch,
-                              uint32_t *h_partial_out) {
+                              uint32_t *h_partial_out) try {
     if (!ctx || !h_share || !d_cc || !h_partial_out || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (batch == 0) return GSW_OK;
     if (int rc = use_device(ctx)) return rc;
@@ -1057,6 +1076,7 @@ int gsw_partial_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_share, const uint3
     memcpy(h_partial_out, raw.data(), sizeof(uint32_t) * (size_t)batch);
     return GSW_OK;
 }
+GSW_CATCH
 
 int gsw_combine_partials(gsw_ctx *ctx, const uint32_t *h_partials, int parties, int batch, uint32_t *h_bits_out) {
     if (!ctx || !h_partials || !h_bits_out || parties < 1 || batch < 0) return fail(GSW_E_INVALID, "bad argument");
@@ -1092,7 +1112,7 @@ int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, 
     return GSW_OK;
 }
 
-int gsw_decrypt_dense(gsw_ctx *ctx, const uint32_t *h_v, const uint32_t *d_c, uint32_t *h_bit_out) {
+int gsw_decrypt_dense(gsw_ctx *ctx, const uint32_t *h_v, const uint32_t *d_c, uint32_t *h_bit_out) try {
     if (!ctx || !h_v || !d_c || !h_bit_out) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     std::vector<uint32_t> raw;
@@ -1100,6 +1120,7 @@ int gsw_decrypt_dense(gsw_ctx *ctx, const uint32_t *h_v, const uint32_t *d_c, ui
     *h_bit_out = is_zero_one(ctx->ring, raw[0]);
     return GSW_OK;
 }
+GSW_CATCH
 
 // ---- sampling and digests ----
 
@@ -1118,7 +1139,7 @@ int gsw_sample_naive(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_o
     return gsw_fill_uniform(ctx, seed, stream, 0, gswk::kFpP >> 15, 1, d_out, count);
 }
 
-int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sigma, uint32_t *d_out, size_t count) {
+int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sigma, uint32_t *d_out, size_t count) try {
     if (!ctx || !d_out || !(sigma > 0.0) || sigma > 300.0) return fail(GSW_E_INVALID, "bad argument (0 < sigma <= 300)");
     if (int rc = use_device(ctx)) return rc;
     std::vector<uint64_t> cum;
@@ -1134,6 +1155,7 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
     HIP_TRY(e);
     return GSW_OK;
 }
+GSW_CATCH
 
 int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size_t bytes, int mode, size_t pitch) {
     if (!ctx || !d_src || (bytes & 0xFFFF) || mode < 0 || mode > 1) return fail(GSW_E_INVALID, "bad argument");
