@@ -24,11 +24,15 @@ template <int SHAPE, int BINARY_A>
 __global__ __launch_bounds__(256, 2) void mfma_loop(const v4i *in, int *out, int iters) {
     v4i a0 = in[threadIdx.x], a1 = in[threadIdx.x + 256], b[4];
     for (int i = 0; i < 4; ++i) b[i] = in[threadIdx.x + 512 + 256 * i];
-    if (BINARY_A) {
+    if (BINARY_A == 1) {
         for (int i = 0; i < 4; ++i) {
             a0[i] &= 0x01010101;
             a1[i] &= 0x01010101;
         }
+    }
+    if (BINARY_A == 2) {  // the binary operand in the B position instead
+        for (int l = 0; l < 4; ++l)
+            for (int i = 0; i < 4; ++i) b[l][i] &= 0x01010101;
     }
     if (SHAPE == 32) {
         v16i acc[8];
@@ -96,5 +100,7 @@ int main(int argc, char **argv) {
     run<32, 1>("32x32x32 i8, A bytes in {0,1}", d_in, d_out, iters, blocks);
     run<16, 0>("16x16x64 i8, random A and B", d_in, d_out, iters, blocks);
     run<16, 1>("16x16x64 i8, A bytes in {0,1}", d_in, d_out, iters, blocks);
+    run<32, 2>("32x32x32 i8, B bytes in {0,1}", d_in, d_out, iters, blocks);
+    run<16, 2>("16x16x64 i8, B bytes in {0,1}", d_in, d_out, iters, blocks);
     return 0;
 }
