@@ -33,3 +33,21 @@ def test_two_rank_rehearsal_prints_one_contract_line():
     assert out["vs_baseline"] is None and out["value"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.gpu
+def test_result_drain_on_the_gpu_without_peers():
+    """The device side of dist.ResultDrain (receive buffers, side stream, pinned host memory) with one rank."""
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from tfhe_amd import dist as gdist
+
+    dev = torch.device("cuda", 0)
+    entries, shape = 7, (33, 20)
+    data = torch.arange(entries * 33 * 20, dtype=torch.int32, device=dev).reshape(entries, *shape)
+    drain = gdist.ResultDrain(shape, torch.int32, world=1, rank=0, entries=entries, chunk=3, device=dev)
+    for scale in (1, 2):  # second call reuses the buffers
+        host = drain.run(data * scale)
+        assert host.is_pinned() and host.shape == (1, entries) + shape
+        assert torch.equal(host[0], (data * scale).cpu())
