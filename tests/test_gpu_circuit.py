@@ -158,3 +158,36 @@ def test_partial_decryptions_of_additive_shares_recombine(oracle, tfhe_amd, ring
         assert gsw.combine_partials(partials).tolist() == bits.tolist()
     with pytest.raises(ValueError):
         gsw.part_dec(np.zeros(3), ct)
+
+
+def test_full_benchmark_batch_through_slot_lists(oracle, tfhe_amd):
+    """1024 products of the n = 256 benchmark shape in one gate list over a pool of 16 operands: entry b
+    multiplies operands (2b mod 16, 2b + 1 mod 16), so the digests must repeat with period 8 (a checksum of
+    checksums over the whole batch), and two full products are compared with the oracle bit for bit."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ring_o, ring_d = oracle.fp(), tfhe_amd.Fp()
+    n, operands, batch = 256, 16, 1024
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=5)
+    eng = gsw.engine
+    pool = tfhe_amd.Ciphertext(eng, operands + batch)
+    _lib.check(L.gsw_memset_zero(eng.handle, pool.ptr, 4 * eng.compact_elems * (operands + batch)))
+    rng = np.random.default_rng(77)
+    host = rng.integers(0, ring_o.q, size=(operands, eng.big_n, n + 1), dtype=np.uint64).astype(np.uint32)
+    for k in range(operands):
+        _lib.check(L.gsw_upload_compact(eng.handle, pool.entry_ptr(k), host[k].ctypes.data))
+    gates = [("mult", (2 * b) % operands, (2 * b + 1) % operands, operands + b) for b in range(batch)]
+    gsw.eval_circuit(pool, gates)
+    digests = eng.alloc(8 * batch)
+    _lib.check(L.gsw_digest_batch(eng.handle, pool.entry_ptr(operands), eng.compact_elems, eng.compact_elems, batch,
+                                  digests.ptr))
+    d = digests.download(np.uint64, batch)
+    assert len(set(d[:8].tolist())) == 8
+    assert np.array_equal(d, np.tile(d[:8], batch // 8))
+    og = oracle.GSW(ring_o, n, n * 31)
+    out = np.empty((eng.big_n, n + 1), dtype=np.uint32)
+    for b in (3, 1020):
+        _lib.check(L.gsw_download_compact(eng.handle, out.ctypes.data, pool.entry_ptr(operands + b)))
+        k = b % 8
+        assert np.array_equal(out, og.mul_gadget(host[2 * k], host[2 * k + 1])), b
