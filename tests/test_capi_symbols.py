@@ -49,3 +49,18 @@ def test_product_package_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("gsw_oracle", "oracle") or "import oracle" not in src, f
                 assert "gsw_oracle" not in src and "libgsw_oracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gsw_hip.h must be consumable by a C compiler (cgo / bindgen / ctypes-style callers)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "gsw_hip.h"\n'
+                   "int probe(gsw_ctx *ctx, gsw_gate *g) {\n"
+                   "    g->op = GSW_GATE_NAND;\n"
+                   "    return gsw_ctx_big_n(ctx) + (int)gsw_wire_bytes(ctx, GSW_WIRE_CIPHERTEXT, 1) + GSW_RING_FP_M31;\n"
+                   "}\n")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
+                    os.path.join(root, "include"), str(src)], check=True)
