@@ -54,7 +54,9 @@ def _assert_equal(got, expect, what):
 @pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9"])
 @pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 1), ("fp", 3), ("fp", 7), ("fp", 32), ("fp", 39),
                                           ("fp", 40), ("fp", 71), ("z30", 10), ("z31", 10), ("z32", 10),
-                                          ("z32", 33), ("z8", 5), ("z2", 9), ("z1", 40)])
+                                          ("z32", 33), ("z8", 5), ("z2", 9), ("z1", 40),
+                                          # last row tile of at most 64 rows (the thin-tile path of variant 9)
+                                          ("fp", 8), ("fp", 16), ("z32", 8)])
 def test_mul_gadget_random_operands(oracle, tfhe_amd, ring_name, n, variant):
     """Pc = BitDecomp(C1c) * C2c on uniform random operands (every bit pattern exercised)."""
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
@@ -185,7 +187,7 @@ def test_keygen_encrypt_decrypt(oracle, tfhe_amd, ring_name, n, sampler):
 
 def test_encrypt_matches_oracle(oracle, tfhe_amd):
     """Batched encryption product R * pk + mu * G against the oracle, R given on the host."""
-    for ring_name, n in (("fp", 10), ("z32", 7)):
+    for ring_name, n in (("fp", 10), ("z32", 7), ("fp", 8)):
         ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
         m = n * ring_d.ell
         og = oracle.GSW(ring_o, n, m, seed=5, check_max=False)
