@@ -749,9 +749,10 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
         if (int rc = ensure_workspace(ctx, 2 * pipe_chunk * prep)) return rc;
         HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
-        size_t k = 0;
-        for (size_t b0 = 0; b0 < (size_t)batch; b0 += pipe_chunk, ++k) {
-            const int cur = (int)((size_t)batch - b0 < pipe_chunk ? (size_t)batch - b0 : pipe_chunk);
+        // the first chunk's preparation is the only one nothing hides: keep it to a quarter chunk
+        size_t k = 0, step = pipe_chunk >= 64 ? pipe_chunk / 4 : pipe_chunk;
+        for (size_t b0 = 0; b0 < (size_t)batch; b0 += step, step = pipe_chunk, ++k) {
+            const int cur = (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step);
             const int half = (int)(k & 1);
             uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
             if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
