@@ -117,6 +117,41 @@ def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
                                                    1, 0))
 
 
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9"])
+@pytest.mark.parametrize("n,align", [(32, "16"), (32, "32"), (39, "16"), (64, "32"), (7, "32")])
+def test_padding_columns_are_written_even_into_a_dirty_buffer(oracle, tfhe_amd, n, align, variant):
+    """The output buffer starts as garbage: every padding column up to the row pitch must come out zero (a
+    packed tail tile computes 8 columns but the pitch can reach 32 past its first), and the digest taken in
+    the epilogue must equal the digest of the stored buffer."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    os.environ["GSW_GEMM_VARIANT"] = variant
+    os.environ["GSW_LD_ALIGN"] = align
+    try:
+        gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
+    finally:
+        os.environ.pop("GSW_GEMM_VARIANT", None)
+        os.environ.pop("GSW_LD_ALIGN", None)
+    eng = gsw.engine
+    og = oracle.GSW(ring_o, n, n * 31)
+    rng = np.random.default_rng(n)
+    c1, c2 = _rand_compact(rng, ring_o, n, 2), _rand_compact(rng, ring_o, n, 2)
+    d1, d2 = tfhe_amd.Ciphertext.from_compact(eng, c1), tfhe_amd.Ciphertext.from_compact(eng, c2)
+    out = tfhe_amd.Ciphertext(eng, 2)
+    out.buf.upload(np.full(2 * eng.compact_elems, 0xDEADBEEF, dtype=np.uint32))
+    dig, dig2 = eng.alloc(16), eng.alloc(16)
+    _lib.check(L.gsw_mul_gadget_batch_digest(eng.handle, d1.ptr, d1.stride, d2.ptr, d2.stride, out.ptr, out.stride, 2,
+                                             0, dig.ptr))
+    raw = out.buf.download(np.uint32, 2 * eng.compact_elems).reshape(2, eng.big_n, eng.ld)
+    assert (raw[:, :, n + 1:] == 0).all(), np.argwhere(raw[:, :, n + 1:] != 0)[:4]
+    for b in range(2):
+        _assert_equal(raw[b, :, :n + 1], og.mul_gadget(c1[b], c2[b]), f"product [{b}]")
+    _lib.check(L.gsw_digest_batch(eng.handle, out.ptr, out.stride, eng.compact_elems, 2, dig2.ptr))
+    assert dig.download(np.uint64, 2).tolist() == dig2.download(np.uint64, 2).tolist()
+
+
 def test_empty_batches_and_ragged_public_keys(oracle, tfhe_amd):
     """batch = 0 is a no-op everywhere; m need not be a multiple of ell (the last word of a row of
     encryption bits is partly used) nor equal n * ell."""

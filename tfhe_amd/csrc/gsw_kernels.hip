@@ -256,6 +256,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
                         const unsigned w = 2u * (unsigned)idx + 1u;
                         dig += (unsigned long long)val * w + w;
                     }
+            } else if (NFRAG == 1 && !col_owner && row < p.rows && c.nt * kTileCols + c32 < p.ld_out) {
+                // a packed tile computes 8 columns; the other lanes zero the rest of the padding columns
+                const size_t idx = (size_t)row * p.ld_out + c.nt * kTileCols + c32;
+                out[idx] = 0u;
+                if (want_digest) dig += 2u * (unsigned)idx + 1u;
             }
         }
     }
@@ -527,6 +532,19 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                         // digest is applied once per wave (multiplication mod 2^64 distributes over the sum)
                         const unsigned w = 2u * (unsigned)idx + 1u;
                         dig += (unsigned long long)val * w + w;
+                    }
+                }
+            }
+            if (PACKED && row < p.rows) {
+                // a packed tile computes 8 columns; zero the padding columns behind them (the row pitch may
+                // reach up to 32 columns past the tile's first)
+#pragma unroll
+                for (int extra = 0; extra < 2; ++extra) {
+                    const int zc = c.nt * kTileCols + extra * 16 + c16;
+                    if ((extra == 1 || c16 >= 8) && zc < p.ld_out) {
+                        const size_t idx = (size_t)row * p.ld_out + zc;
+                        out[idx] = 0u;
+                        if (want_digest) dig += 2u * (unsigned)idx + 1u;
                     }
                 }
             }
