@@ -152,6 +152,28 @@ def test_padding_columns_are_written_even_into_a_dirty_buffer(oracle, tfhe_amd, 
     assert dig.download(np.uint64, 2).tolist() == dig2.download(np.uint64, 2).tolist()
 
 
+def test_bit_decomp_inv_writes_the_padding_columns(oracle, tfhe_amd):
+    """Dense -> compact conversion into a dirty buffer: padding columns come out zero."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 4
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
+    eng = gsw.engine
+    rng = np.random.default_rng(2)
+    cc = _rand_compact(rng, ring_o, n)
+    dense = oracle.bit_decomp_matrix(ring_o, cc)
+    d_dense = eng.alloc_u32(dense.size)
+    d_dense.upload(np.ascontiguousarray(dense, dtype=np.uint32))
+    out = tfhe_amd.Ciphertext(eng, 1)
+    out.buf.upload(np.full(eng.compact_elems, 0xDEADBEEF, dtype=np.uint32))
+    _lib.check(L.gsw_bit_decomp_inv(eng.handle, d_dense.ptr, eng.big_n, n + 1, out.ptr, eng.ld, 0))
+    raw = out.buf.download(np.uint32, eng.compact_elems).reshape(eng.big_n, eng.ld)
+    _assert_equal(raw[:, :n + 1], cc, "BitDecomp^-1(BitDecomp(Cc))")
+    assert eng.ld > n + 1 and (raw[:, n + 1:] == 0).all()
+
+
 def test_empty_batches_and_ragged_public_keys(oracle, tfhe_amd):
     """batch = 0 is a no-op everywhere; m need not be a multiple of ell (the last word of a row of
     encryption bits is partly used) nor equal n * ell."""

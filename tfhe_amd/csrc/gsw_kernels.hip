@@ -1582,10 +1582,15 @@ __global__ void bit_decomp_kernel(const uint32_t *in, int rows, int cols, int ld
 template <int RING>
 __global__ void bit_decomp_inv_kernel(const uint32_t *in, int rows, int cols, uint32_t *out, int ld_out, int quirk,
                                       int ell, uint32_t mask) {
-    const size_t total = (size_t)rows * cols;
+    // every column up to the leading dimension is written: the padding columns of a compact ciphertext are zero
+    const size_t total = (size_t)rows * ld_out;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = idx / cols, j = idx - i * cols;
+        const size_t i = idx / ld_out, j = idx - i * ld_out;
+        if (j >= (size_t)cols) {
+            out[idx] = 0u;
+            continue;
+        }
         const uint32_t *chunk = in + (i * cols + j) * ell;
         uint32_t res;
         if (quirk) {
