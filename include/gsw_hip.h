@@ -109,7 +109,8 @@ int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uin
 
 /* ---- the hot path: Pc = G^-1(C1c) * C2c mod q on int8 MFMA (gsw_impl.rs:104-123 via the
  *      identity above).  Strides are in uint32 elements between consecutive batch entries;
- *      a stride of 0 reuses one operand for the whole batch. ---- */
+ *      a stride of 0 reuses one operand for the whole batch.  The output may not share memory with
+ *      an operand (GSW_E_INVALID): the reference returns a fresh matrix (gsw_impl.rs:107). ---- */
 /* limb-split one or more compact right operands into prepared form */
 int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch);
 int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,

@@ -112,6 +112,11 @@ def test_mul_gadget_padding_stays_zero_and_strides(oracle, tfhe_amd):
         _assert_equal(out.to_compact()[b], og.mul_gadget(c1[b], c2, flags=oracle.FLAG_NAND), f"nand+digest [{b}]")
     # empty batch is a no-op
     _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, out.ptr, out.stride, 0, 0))
+    # an output that shares memory with an operand is refused (tiles are written while others still read)
+    for dst, count in ((d1.ptr, 1), (d1.entry_ptr(3), 4), (d2.ptr, 1)):
+        with pytest.raises(tfhe_amd.GswError, match="overlaps"):
+            _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr, d1.stride, d2.ptr, 0, dst, out.stride,
+                                                       count, 0))
     with pytest.raises(tfhe_amd.GswError):
         _lib.check(_lib.lib().gsw_mul_gadget_batch(eng.handle, d1.ptr + 4, d1.stride, d2.ptr, 0, out.ptr, out.stride,
                                                    1, 0))

@@ -127,6 +127,7 @@ struct ScopedTimer {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
 // checks shared by the two contraction entry points
 int check_gemm_common(const gsw_ctx *ctx, const void *lhs, size_t stride1, const void *out, size_t stride_out,
                       int batch, unsigned flags) {
@@ -140,6 +141,19 @@ int check_gemm_common(const gsw_ctx *ctx, const void *lhs, size_t stride1, const
     if (stride_out < gsw_ctx_compact_elems(ctx) && batch > 1)
         return fail(GSW_E_INVALID, "output stride %zu smaller than one ciphertext (%zu)", stride_out,
                     gsw_ctx_compact_elems(ctx));
+    return GSW_OK;
+}
+
+// Products are written tile by tile while other tiles still read the operands: the output may not share
+// memory with an operand (the reference returns a fresh matrix, gsw_impl.rs:107).
+int check_no_alias(const gsw_ctx *ctx, const uint32_t *operand, size_t stride, size_t operand_elems, const uint32_t *out,
+                   size_t stride_out, int batch, const char *which) {
+    const size_t elems = gsw_ctx_compact_elems(ctx);
+    if (batch <= 0 || !operand || !out) return GSW_OK;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(operand), b0 = reinterpret_cast<uintptr_t>(out);
+    const uintptr_t a1 = a0 + 4 * ((size_t)(batch - 1) * stride + operand_elems);
+    const uintptr_t b1 = b0 + 4 * ((size_t)(batch - 1) * stride_out + elems);
+    if (a0 < b1 && b0 < a1) return fail(GSW_E_INVALID, "the output overlaps the %s operand", which);
     return GSW_OK;
 }
 
@@ -712,6 +726,9 @@ static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, con
 int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
                             size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch,
                             unsigned flags) {
+    if (ctx && batch > 0)
+        if (int rc = check_no_alias(ctx, d_c1c, stride1, gsw_ctx_compact_elems(ctx), d_out, stride_out, batch, "left"))
+            return rc;
     return mul_prepared(ctx, d_c1c, stride1, d_prepared, stride_prepared_bytes, d_out, stride_out, batch, flags,
                         nullptr);
 }
@@ -729,6 +746,11 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
+    if (!slots) {  // gate lists check slot numbers instead
+        const size_t elems = gsw_ctx_compact_elems(ctx);
+        if (int rc = check_no_alias(ctx, d_c1c, stride1, elems, d_out, stride_out, batch, "left")) return rc;
+        if (int rc = check_no_alias(ctx, d_c2c, stride2, elems, d_out, stride_out, batch, "right")) return rc;
+    }
     if (int rc = use_device(ctx)) return rc;
     if (d_digests) HIP_TRY(hipMemsetAsync(d_digests, 0, sizeof(uint64_t) * (size_t)batch, ctx->stream));
     const size_t prep = gsw_ctx_prepared_bytes(ctx);
