@@ -3,7 +3,7 @@
 
 A step is one pass of the hot path over one batch of synthetic input resident in HBM:
 `batch` independent products Pc = G^-1(C1c) * C2c mod q (right-operand preparation + int8-MFMA
-contraction, whose epilogue also accumulates a 64-bit digest of every product).  Default workload: BASELINE.json configs[1],
+contraction, whose epilogue also accumulates a 64-bit digest of every product).  Default workload: the headline configuration,
 batch 1024, n = 256, p = 2^31 - 1, on one GPU.  With N > 1 every rank runs its own batch (weak
 scaling, no collective inside the contraction) and the digests plus one sampled product per rank
 are gathered to rank 0 over RCCL inside the timed region.
@@ -39,10 +39,10 @@ KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined
 
 WORKLOADS = {
     # name: (ring, n, default batch)
-    "fp_n256": (lambda: tfhe_amd.Fp(), 256, 1024),      # BASELINE.json configs[1]
-    "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # configs[2] shape, per-GPU slice
-    "z32_n512": (lambda: tfhe_amd.Zpow2(32), 512, 256),  # configs[4] shape
-    "fp_n10": (lambda: tfhe_amd.Fp(), 10, 1024),        # configs[0] shape (plumbing)
+    "fp_n256": (lambda: tfhe_amd.Fp(), 256, 1024),      # the headline configuration: 1024 products, n = 256, p < 2^31
+    "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # the 8-GPU configuration's shape (n = 512), per-GPU slice
+    "z32_n512": (lambda: tfhe_amd.Zpow2(32), 512, 256),  # the power-of-two ring configuration's shape (q = 2^32, n = 512)
+    "fp_n10": (lambda: tfhe_amd.Fp(), 10, 1024),        # the reference's own test parameters (plumbing)
 }
 
 

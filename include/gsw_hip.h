@@ -4,7 +4,7 @@
  * The reference crate has no FFI; the boundary these entry points replace is the Rust
  * trait `FheScheme<R>` as implemented for `GSW<R, T>` (src/gsw/mod.rs:12-26,
  * src/gsw/gsw_impl.rs:12-125).  A Rust shim implements that trait on top of this header
- * (see INTEGRATION.md).  Every entry point below cites the reference lines it stands for.
+ * (integration/rust/hip.rs).  Every entry point below cites the reference lines it stands for.
  *
  * Element type.  The reference's `R: RingElement` (src/lib.rs:15-29) is `Fp`
  * (src/field.rs:7-19, p = 2^31 - 1, stored in Montgomery form) or `Zpow2<M>`
