@@ -8,6 +8,13 @@ batch 1024, n = 256, p = 2^31 - 1, on one GPU.  With N > 1 every rank runs its o
 scaling, no collective inside the contraction) and the digests plus one sampled product per rank
 are gathered to rank 0 over RCCL inside the timed region.
 
+`--config K` selects configuration K of the benchmark list at its real per-GPU size: 2 = the default;
+3 = 16 384 products of n = 512 over Fp sharded over 8 GPUs, i.e. 2 048 per GPU; 5 = 4 096 products of
+n = 512 over Z/2^32.
+
+The engine and every torch operation of this file run on ONE explicit (non-default) HIP stream, so the
+operand fill, the contraction, the gather and the checks are ordered by the stream itself.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -40,9 +47,15 @@ KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined
 WORKLOADS = {
     # name: (ring, n, default batch)
     "fp_n256": (lambda: tfhe_amd.Fp(), 256, 1024),      # the headline configuration: 1024 products, n = 256, p < 2^31
-    "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # the 8-GPU configuration's shape (n = 512), per-GPU slice
+    "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # the 8-GPU configuration's shape (n = 512), a short batch
     "z32_n512": (lambda: tfhe_amd.Zpow2(32), 512, 256),  # the power-of-two ring configuration's shape (q = 2^32, n = 512)
     "fp_n10": (lambda: tfhe_amd.Fp(), 10, 1024),        # the reference's own test parameters (plumbing)
+}
+# --config K: configuration K (1-based) of the benchmark list at its real per-GPU size -> (workload, batch per GPU, pool)
+CONFIGS = {
+    2: ("fp_n256", 1024, 2048),   # 1024 products, n = 256, one GPU (the default)
+    3: ("fp_n512", 2048, 1024),   # 16 384 products over 8 GPUs = 2 048 per GPU; pool of 1024 ciphertexts (34 GB)
+    5: ("z32_n512", 4096, 1024),  # 4 096 products, q = 2^32, n = 512; outputs 142 GB + pool 36 GB of 288 GB
 }
 
 
@@ -51,6 +64,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
+                    help="benchmark configuration (1-based) at its real per-GPU size; overrides --workload, and "
+                         "gives the defaults of --batch / --pool")
     ap.add_argument("--workload", default="fp_n256", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="products per GPU per step (default: the workload's)")
     ap.add_argument("--pool", type=int, default=0, help="distinct resident ciphertexts (default 2 * batch, capped)")
@@ -94,7 +110,10 @@ def cpu_baseline(engine, ring, n, pool_t, lhs_idx, rhs_idx, out_t, seconds: floa
     bounded sample of the same workload and checks the GPU's products against it bit for bit."""
     from oracle import gsw_oracle as O  # the checker / CPU baseline: the only use of the oracle in this file
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # every core this process may use: OMP_NUM_THREADS when the box sets it (its share of a shared machine),
+    # else the scheduler's affinity mask
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or avail
     ring_o = O.fp() if ring.kind == _lib.RING_FP_M31 else O.zpow2(ring.log2q)
     og = O.GSW(ring_o, n, n * ring_o.ell)
     width = n + 1
@@ -128,7 +147,8 @@ def cpu_baseline(engine, ring, n, pool_t, lhs_idx, rhs_idx, out_t, seconds: floa
     dense_s = time.perf_counter() - t0
     big_n = ring_o.big_n(n)
     return {
-        "value": count / total, "unit": "mults/s", "cores": threads, "kind": "port",
+        "value": count / total, "unit": "mults/s", "cores": threads, "host_cores": os.cpu_count(),
+        "cores_available_to_this_process": avail, "kind": "port",
         "sample": f"{count} products of the same pool (n={n}, N={big_n}) through the compact-form CPU port, "
                   f"OpenMP over the batch, {total:.1f} s",
         "gpu_matches_cpu_bit_exact": verified,
@@ -151,7 +171,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    make_ring, n, default_batch = WORKLOADS[args.workload]
+    pool_default = 0
+    if args.config:
+        args.workload, default_batch, pool_default = CONFIGS[args.config]
+        make_ring, n, _ = WORKLOADS[args.workload]
+    else:
+        make_ring, n, default_batch = WORKLOADS[args.workload]
     ring = make_ring()
     batch = args.batch or default_batch
     if args.variant is not None:
@@ -159,13 +184,26 @@ def main():
     gsw = tfhe_amd.GSW(ring, n, n * ring.ell, seed=0x6A5C0000 + rank, device=local_rank)
     eng, L = gsw.engine, _lib.lib()
     variant = L.gsw_ctx_gemm_variant(eng.handle)  # chosen by shape unless GSW_GEMM_VARIANT says otherwise
-    stream = torch.cuda.current_stream(dev)
+    # One explicit stream for the engine and for torch.  Torch's default stream has the handle NULL, which
+    # the engine reads as "use your own stream": work on the two would then be unordered.
+    stream = torch.cuda.Stream(dev)
     eng.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        result = run(args, gsw, ring, n, batch, pool_default, variant, rank, world, dev, rehearsal)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    gdist.barrier()
+    gdist.shutdown()
+
+
+def run(args, gsw, ring, n, batch, pool_default, variant, rank, world, dev, rehearsal):
+    eng, L = gsw.engine, _lib.lib()
     big_n, ld, ct = eng.big_n, eng.ld, eng.compact_elems
-    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, max(batch * eng.prepared_bytes, eng.prepared_bytes)))
+    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, max(min(batch, 256) * eng.prepared_bytes, eng.prepared_bytes)))
 
     # resident pool of synthetic compact ciphertexts: i.i.d. uniform in [0, q), padding columns zero
-    pool = args.pool or min(2 * batch, 2048)
+    pool = args.pool or pool_default or min(2 * batch, 2048)
+    pool -= pool % 2
     pool_t = torch.empty((pool, big_n, ld), dtype=torch.int32, device=dev)
     _lib.check(L.gsw_fill_uniform(eng.handle, 0x6A5C0000 + 1, rank, 0, ring.max_u64(), 1, pool_t.data_ptr(),
                                   pool * ct))
@@ -175,6 +213,10 @@ def main():
     elif args.diag_pool == "sparse":  # one bit set per element
         pool_t.copy_(torch.ones_like(pool_t) << (pool_t & 7))
         pool_t[:, :, n + 1:] = 0
+    bad = C.c_uint64(0)
+    _lib.check(L.gsw_validate_compact(eng.handle, pool_t.data_ptr(), ct, pool, C.byref(bad)))
+    if bad.value:
+        raise SystemExit(f"operand pool breaks the contraction's invariants in {bad.value} words")
     out_t = torch.empty((batch, big_n, ld), dtype=torch.int32, device=dev)
     digests = torch.zeros(batch, dtype=torch.int64, device=dev)
     lhs_idx = [(2 * b) % pool for b in range(batch)]
@@ -186,6 +228,7 @@ def main():
     drain = None
     if args.gather == "full":
         drain = gdist.ResultDrain((big_n, ld), torch.int32, world, rank, batch, chunk=32, device=dev)
+    gathered = {}
 
     def step():
         for b0 in range(0, batch, per_call):
@@ -194,12 +237,13 @@ def main():
                                                      pool_t.data_ptr() + 4 * ct, 2 * ct,
                                                      out_t.data_ptr() + 4 * ct * b0, ct, cur, 0,
                                                      digests.data_ptr() + 8 * b0))
+        # the exchange step follows the contraction on the same stream
         if drain is not None:
-            drain.run(out_t)  # every product of every rank to rank 0's host memory
+            gathered["full"] = drain.run(out_t)  # every product of every rank to rank 0's host memory
         elif world > 1:
-            # the only exchange step: digests of every product + one sampled product per rank to rank 0
-            gdist.gather_to_root(digests)
-            gdist.gather_to_root(out_t[0])
+            # digests of every product + one sampled product per rank to rank 0
+            gathered["digests"] = gdist.gather_to_root(digests)
+            gathered["sample"] = gdist.gather_to_root(out_t[0])
 
     for _ in range(args.warmup):
         step()
@@ -219,40 +263,62 @@ def main():
     prep_ms, prep_launches = eng.kernel_time(1)
     eng.enable_timing(False)
 
-    if rank == 0:
-        total_mults = world * batch * args.steps
-        mults_per_launch = batch * args.steps / max(gemm_launches, 1)
-        gemm_avg_s = gemm_ms / 1e3 / max(gemm_launches, 1)
-        achieved_tops = algorithmic_ops(big_n, n) * mults_per_launch / gemm_avg_s / 1e12 if gemm_avg_s > 0 else 0.0
-        result = {
-            "metric": "GSW ciphertext mults/sec (node)", "value": total_mults / elapsed, "unit": "mults/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int8",  # int8 MFMA, exact int32 accumulation, u32 ring elements
-            "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
-            "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
-                                   f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
-                       "batch_per_gpu": batch, "pool": pool, "gather": args.gather, "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
-            "roofline": {
-                "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),
-                "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
-                "op_kind": "int8 MFMA multiply-accumulate (exact int32 accumulation, u32 ring elements) counted as "
-                           "2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
-                "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} of a -DGSW_DIAGNOSTIC_BUILDS library (wrong results by design)"),
-                "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
-                "products_per_launch": mults_per_launch,
-                "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),
-                "algorithmic_bytes_per_product": algorithmic_bytes(big_n, n),
-                "hbm_gbs_algorithmic": algorithmic_bytes(big_n, n) * total_mults / world / elapsed / 1e9,
-                "hbm_peak_gbs": HBM_PEAK_GBS,
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(eng, ring, n, pool_t, lhs_idx, rhs_idx, out_t, args.cpu_seconds)
-        print(json.dumps(result), flush=True)
-    gdist.barrier()
-    gdist.shutdown()
+    # Untimed check of what the last step left behind: the fused digests equal the digest kernel's over the
+    # stored products, and what rank 0 gathered is what the ranks hold (its own digests entry for entry; for
+    # every rank, the digest of the gathered sample product equals that rank's gathered digest 0).
+    check = torch.zeros(batch, dtype=torch.int64, device=dev)
+    _lib.check(L.gsw_digest_batch(eng.handle, out_t.data_ptr(), ct, ct, batch, check.data_ptr()))
+    exchange_ok = bool(torch.equal(check, digests))
+    if rank == 0 and gathered.get("digests") is not None:
+        got = gathered["digests"]
+        exchange_ok = exchange_ok and bool(torch.equal(got[0].to(dev), digests))
+        one = torch.zeros(1, dtype=torch.int64, device=dev)
+        for r, sample in enumerate(gathered["sample"]):
+            sample = sample.to(dev).contiguous()
+            _lib.check(L.gsw_digest_batch(eng.handle, sample.data_ptr(), ct, ct, 1, one.data_ptr()))
+            exchange_ok = exchange_ok and int(one.item()) == int(got[r][0].item())
+    if rank == 0 and gathered.get("full") is not None:
+        exchange_ok = exchange_ok and bool(torch.equal(gathered["full"][0].to(dev), out_t))
+    torch.cuda.synchronize(dev)
+
+    if rank != 0:
+        return None
+    total_mults = world * batch * args.steps
+    mults_per_launch = batch * args.steps / max(gemm_launches, 1)
+    gemm_avg_s = gemm_ms / 1e3 / max(gemm_launches, 1)
+    achieved_tops = algorithmic_ops(big_n, n) * mults_per_launch / gemm_avg_s / 1e12 if gemm_avg_s > 0 else 0.0
+    result = {
+        "metric": "GSW ciphertext mults/sec (node)", "value": total_mults / elapsed, "unit": "mults/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8",  # int8 MFMA, exact int32 accumulation, u32 ring elements
+        "data": "synthetic" if args.diag_pool == "uniform" else f"DIAGNOSTIC pool pattern {args.diag_pool}: not the benchmark",
+        "config": {"workload": f"{args.workload}: batch {batch} per GPU of independent GSW products, n={n}, "
+                               f"ell={ring.ell}, N={big_n}, q={'2^31-1' if ring.kind == 0 else '2^%d' % ring.log2q}",
+                   "benchmark_config": args.config or (2 if args.workload == "fp_n256" and batch == 1024 else None),
+                   "batch_per_gpu": batch, "pool": pool, "gather": args.gather,
+                   "exchange_verified": exchange_ok,
+                   "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
+        "roofline": {
+            "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",
+            "frac": achieved_tops / INT8_DENSE_PEAK_TOPS, "traffic": load_traffic(args.workload, variant, mults_per_launch),
+            "algorithmic_bytes_per_launch": algorithmic_bytes(big_n, n) * mults_per_launch,
+            "op_kind": "int8 MFMA multiply-accumulate (exact int32 accumulation, u32 ring elements) counted as "
+                       "2 ops; algorithmic ops 2*N^2*(n+1)*4 per product",
+            "kernel": KERNEL_NAMES.get(variant, f"diagnostic build {variant} of a -DGSW_DIAGNOSTIC_BUILDS library (wrong results by design)"),
+            "kernel_variant": variant, "kernel_avg_ms": gemm_avg_s * 1e3, "launches": gemm_launches,
+            "products_per_launch": mults_per_launch,
+            "prepare_kernel_avg_ms": prep_ms / max(prep_launches, 1),
+            "algorithmic_bytes_per_product": algorithmic_bytes(big_n, n),
+            "hbm_gbs_algorithmic": algorithmic_bytes(big_n, n) * total_mults / world / elapsed / 1e9,
+            "hbm_peak_gbs": HBM_PEAK_GBS,
+        },
+    }
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(eng, ring, n, pool_t, lhs_idx, rhs_idx, out_t, args.cpu_seconds)
+    if not exchange_ok:
+        raise SystemExit("the digests or gathered results do not match the stored products: " + json.dumps(result))
+    return result
 
 
 if __name__ == "__main__":

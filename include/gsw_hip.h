@@ -58,7 +58,10 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
 void gsw_ctx_destroy(gsw_ctx *ctx);
 const char *gsw_last_error(void);
 const char *gsw_version(void);
-/* use the caller's hipStream_t (e.g. the framework's current stream); NULL restores the context's own */
+/* use the caller's hipStream_t (e.g. the framework's current stream); NULL restores the context's own
+ * stream.  The legacy default stream has the handle NULL and therefore cannot be selected: a caller whose
+ * other work runs there either passes an explicit stream it also uses for that work, or brackets the
+ * calls with gsw_sync() / its own device synchronisation. */
 int gsw_ctx_set_stream(gsw_ctx *ctx, void *hip_stream);
 int gsw_sync(gsw_ctx *ctx);
 int gsw_ctx_ell(const gsw_ctx *ctx);               /* R::Num_Bits (field.rs:39, pow2_ring.rs:19)   */
@@ -111,6 +114,14 @@ int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uin
  *      identity above).  Strides are in uint32 elements between consecutive batch entries;
  *      a stride of 0 reuses one operand for the whole batch.  The output may not share memory with
  *      an operand (GSW_E_INVALID): the reference returns a fresh matrix (gsw_impl.rs:107). ---- */
+/* Invariants of the operands, relied upon but not tested by the contraction (gsw_validate_compact tests
+ * them): every word is a canonical ring value (no bit at or above ell), and every padding word of a row
+ * (columns n + 1 .. ld - 1) is zero.  A stray bit in the left operand would be counted by the signed-limb
+ * correction without a matching limb and shift every limb of that row by a multiple of 128.  Everything
+ * this library writes keeps the invariant; a caller that fills a buffer itself must zero the padding. */
+/* *h_bad_out = number of words, over `batch` compact ciphertexts, that are not canonical or are non-zero
+ * padding.  Waits for the stream. */
+int gsw_validate_compact(gsw_ctx *ctx, const uint32_t *d_cc, size_t stride, int batch, uint64_t *h_bad_out);
 /* limb-split one or more compact right operands into prepared form */
 int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch);
 int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,

@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before the engine library: torch ships its own HIP runtime under the same soname as
+#                 the system's, and whichever is loaded first serves both; torch only finds the GPU through its own
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

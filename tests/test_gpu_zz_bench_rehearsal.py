@@ -13,14 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_two_rank_rehearsal_prints_one_contract_line():
+@pytest.mark.parametrize("workload_args,expect_config", [
+    (["--workload", "fp_n10", "--batch", "64"], None),
+    (["--config", "3", "--batch", "4", "--pool", "8"], 3),  # the 8-GPU configuration's preset, cut down
+    (["--config", "5", "--batch", "4", "--pool", "8"], 5),  # the power-of-two ring configuration's preset, cut down
+])
+def test_two_rank_rehearsal_prints_one_contract_line(workload_args, expect_config):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, GSW_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--workload", "fp_n10", "--batch", "64"]
+           "--warmup", "1"] + workload_args
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -32,6 +37,9 @@ def test_two_rank_rehearsal_prints_one_contract_line():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["vs_baseline"] is None and out["value"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    # rank 0 compared what it gathered (every rank's digests and sampled product) with the stored products
+    assert out["config"]["exchange_verified"] is True and out["config"]["benchmark_config"] == expect_config
+    assert out["roofline"]["unit"] == "TOP/s"
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gsw_mult_const": (_i, [_vp, _vp, _u32, _sz]),
     "gsw_mul_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
     "gsw_nand_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "gsw_validate_compact": (_i, [_vp, _vp, _sz, _i, C.POINTER(_u64)]),
     "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),

@@ -68,6 +68,8 @@ struct gsw_ctx {
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
+    void *small;         // scratch of the helpers that return values to the host (row dots, tables, staging)
+    size_t small_bytes;
     int gemm_variant;
     bool packed_tail;  // the last column tile of prepared operands is stored packed
     bool timing;
@@ -98,6 +100,33 @@ int ensure_workspace(gsw_ctx *ctx, size_t bytes) {
     HIP_TRY(hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
     return GSW_OK;
+}
+
+// Scratch for the helpers around the hot path (decrypt's row dots, key vectors, sampler tables): kept by the
+// context and grown on demand, so that a decrypt inside a chain loop allocates nothing after its first call.
+// Every user enqueues on ctx->stream, which orders successive uses.
+int ensure_small(gsw_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->small_bytes) return GSW_OK;
+    if (ctx->small) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->small));
+        ctx->small = nullptr;
+        ctx->small_bytes = 0;
+    }
+    size_t want = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes + bytes / 2;
+    want = (want + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc(&ctx->small, want));
+    ctx->small_bytes = want;
+    return GSW_OK;
+}
+
+// Makes ctx->stream wait for everything enqueued on the auxiliary stream so far.  Error returns from
+// the two-stream pipeline go through here: no preparation is left running unordered with later work.
+void join_aux(gsw_ctx *ctx) {
+    if (hipEventRecord(ctx->ev_entry, ctx->aux_stream) == hipSuccess)
+        (void)hipStreamWaitEvent(ctx->stream, ctx->ev_entry, 0);
+    else
+        (void)hipStreamSynchronize(ctx->aux_stream);
 }
 
 struct ScopedTimer {
@@ -190,6 +219,18 @@ void gaussian_table(double sigma, std::vector<uint64_t> &cum, int &kmax) {
     cum[len - 1] = 0xFFFFFFFFFFFFFFFFull;
 }
 
+// streams and events of a context; null handles (never created) are skipped
+void destroy_handles(gsw_ctx *ctx) {
+    if (ctx->ev_entry) (void)hipEventDestroy(ctx->ev_entry);
+    if (ctx->ev_slots) (void)hipEventDestroy(ctx->ev_slots);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_prep[i]) (void)hipEventDestroy(ctx->ev_prep[i]);
+        if (ctx->ev_gemm[i]) (void)hipEventDestroy(ctx->ev_gemm[i]);
+    }
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,6 +273,12 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
         if (align != 4 && align != 8 && align != 16 && align != 32) align = 16;
         ctx->ld = (n + 1 + align - 1) / align * align;
     }
+    // element indices inside one compact ciphertext stay below 2^31: the contraction's fused digest weighs
+    // element i with the 32-bit value 2 i + 1, which equals the 64-bit weight of gsw_digest_batch only there
+    if ((uint64_t)ctx->big_n * (uint64_t)ctx->ld >= (1ull << 31)) {
+        delete ctx;
+        return fail(GSW_E_INVALID, "n=%d too large: a compact ciphertext must hold fewer than 2^31 words", n);
+    }
     ctx->words = (m + ring.ell - 1) / ring.ell;
     ctx->ld_r = (ctx->words + 3) & ~3;
     ctx->device = device;
@@ -243,13 +290,15 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->timing = false;
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
 #ifdef GSW_DIAGNOSTIC_BUILDS
-    const bool diagnostic = ctx->gemm_variant >= 10 && ctx->gemm_variant < 138;  // timing-only, wrong results
+    // superseded kernels 0..8 and timing-only builds 10.. (wrong results by design) exist in this library
+    const bool known = ctx->gemm_variant >= 0 && ctx->gemm_variant < 138;
 #else
-    const bool diagnostic = false;
+    const bool known = ctx->gemm_variant == 9 || ctx->gemm_variant == 2 || ctx->gemm_variant == 3;
 #endif
-    if ((ctx->gemm_variant < 0 || ctx->gemm_variant > 9) && !diagnostic) {
+    if (!known) {
         delete ctx;
-        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 0..9");
+        return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 9 (default), 2 or 3 (simple cross-check kernels); the "
+                                   "superseded kernels exist only in a -DGSW_DIAGNOSTIC_BUILDS library");
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
@@ -261,6 +310,7 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gemm[i], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
+        destroy_handles(ctx);  // whatever was created before the failure
         delete ctx;
         return fail(GSW_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
@@ -287,16 +337,10 @@ void gsw_ctx_destroy(gsw_ctx *ctx) {
             (void)hipEventDestroy(t.stop);
         }
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->small) (void)hipFree(ctx->small);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->h_slots) (void)hipHostFree(ctx->h_slots);
-    (void)hipEventDestroy(ctx->ev_entry);
-    (void)hipEventDestroy(ctx->ev_slots);
-    for (int i = 0; i < 2; ++i) {
-        (void)hipEventDestroy(ctx->ev_prep[i]);
-        (void)hipEventDestroy(ctx->ev_gemm[i]);
-    }
-    (void)hipStreamDestroy(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->own_stream);
+    destroy_handles(ctx);
     delete ctx;
 }
 
@@ -496,8 +540,12 @@ int wire_check(const gsw_ctx *ctx, int kind, const uint8_t *buf, size_t bytes, u
         return fail(GSW_E_INVALID, "wire object is %u x %u, expected %u x %u", get_u32(buf + 16), get_u32(buf + 20),
                     sh.rows, sh.cols);
     const uint32_t cnt = get_u32(buf + 24);
-    const size_t elems = (size_t)cnt * sh.rows * sh.cols;
     if (kind != GSW_WIRE_CIPHERTEXT && cnt != 1) return fail(GSW_E_INVALID, "a key object holds exactly one entry");
+    // the count is untrusted: bound it by the bytes at hand before multiplying
+    const size_t per_entry = (size_t)sh.rows * sh.cols;
+    if (per_entry == 0 || cnt > (bytes - kWireHeader - kWireTrailer) / 4 / per_entry)
+        return fail(GSW_E_INVALID, "wire object is %zu bytes, too short for the %u entries its header names", bytes, cnt);
+    const size_t elems = (size_t)cnt * per_entry;
     if (bytes != kWireHeader + 4 * elems + kWireTrailer)
         return fail(GSW_E_INVALID, "wire object is %zu bytes, its header implies %zu", bytes,
                     kWireHeader + 4 * elems + kWireTrailer);
@@ -618,13 +666,10 @@ int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols) {
     if (!ctx || !d_mat || rows < 0 || cols < 0) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     // helper.rs:51-54: bit_decomp_inv then bit_decomp, through a rows x cols scratch matrix
-    uint32_t *tmp = nullptr;
-    HIP_TRY(hipMalloc((void **)&tmp, (size_t)rows * cols * 4 + 16));
-    hipError_t e = gswk::launch_bit_decomp_inv(ctx->ring, d_mat, rows, cols, tmp, cols, 1, ctx->stream);
-    if (e == hipSuccess) e = gswk::launch_bit_decomp(ctx->ring, tmp, rows, cols, cols, d_mat, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    HIP_TRY(e);
+    if (int rc = ensure_small(ctx, (size_t)rows * cols * 4 + 16)) return rc;
+    uint32_t *tmp = (uint32_t *)ctx->small;
+    HIP_TRY(gswk::launch_bit_decomp_inv(ctx->ring, d_mat, rows, cols, tmp, cols, 1, ctx->stream));
+    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, tmp, rows, cols, cols, d_mat, ctx->stream));
     return GSW_OK;
 }
 
@@ -685,6 +730,22 @@ static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c
     a.layout16 = ctx->gemm_variant >= 4;
     a.src_slot = d_slots;
     return run_prepare(ctx, a, stream);
+}
+
+int gsw_validate_compact(gsw_ctx *ctx, const uint32_t *d_cc, size_t stride, int batch, uint64_t *h_bad_out) {
+    if (!ctx || !h_bad_out || batch < 0 || (batch > 0 && !d_cc)) return fail(GSW_E_INVALID, "bad argument");
+    *h_bad_out = 0;
+    if (batch == 0) return GSW_OK;
+    if (stride < gsw_ctx_compact_elems(ctx) && batch > 1) return fail(GSW_E_INVALID, "stride smaller than one ciphertext");
+    if (int rc = use_device(ctx)) return rc;
+    if (int rc = ensure_small(ctx, 256)) return rc;
+    unsigned long long *d_bad = (unsigned long long *)ctx->small;
+    HIP_TRY(gswk::launch_validate(ctx->ring, d_cc, stride, ctx->big_n, ctx->width, ctx->ld, batch, d_bad, ctx->stream));
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *h_bad_out = bad;
+    return GSW_OK;
 }
 
 int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch) {
@@ -769,28 +830,36 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
         // stream beside the (MFMA-bound) contraction of chunk k; two workspace halves, events for the
         // hand-offs in both directions, no host synchronisation.
         if (int rc = ensure_workspace(ctx, 2 * pipe_chunk * prep)) return rc;
-        HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
-        // the first chunk's preparation is the only one nothing hides: keep it to a quarter chunk
-        size_t k = 0, step = pipe_chunk >= 64 ? pipe_chunk / 4 : pipe_chunk;
-        for (size_t b0 = 0; b0 < (size_t)batch; b0 += step, step = pipe_chunk, ++k) {
-            const int cur = (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step);
-            const int half = (int)(k & 1);
-            uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
-            if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
-            const size_t o = slots ? 0 : b0;  // with slot lists the bases stay put and the lists advance
-            if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ws, cur, ctx->aux_stream,
-                                        slots ? slots.rhs + b0 : nullptr))
-                return rc;
-            HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
-            if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ws, prep, d_out + o * stride_out, stride_out,
-                                      cur, flags, d_digests ? d_digests + b0 : nullptr,
-                                      slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
-                return rc;
-            HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
-        }
-        return GSW_OK;
+        // The pipeline body reports failures through its return value; whatever it had enqueued on the
+        // auxiliary stream by then is joined into ctx->stream below, so that no preparation keeps writing
+        // a workspace half unordered with the caller's next call.
+        auto pipeline = [&]() -> int {
+            HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
+            // the first chunk's preparation is the only one nothing hides: keep it to a quarter chunk
+            size_t k = 0, step = pipe_chunk >= 64 ? pipe_chunk / 4 : pipe_chunk;
+            for (size_t b0 = 0; b0 < (size_t)batch; b0 += step, step = pipe_chunk, ++k) {
+                const int cur = (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step);
+                const int half = (int)(k & 1);
+                uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
+                if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
+                const size_t o = slots ? 0 : b0;  // with slot lists the bases stay put and the lists advance
+                if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ws, cur, ctx->aux_stream,
+                                            slots ? slots.rhs + b0 : nullptr))
+                    return rc;
+                HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
+                if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ws, prep, d_out + o * stride_out,
+                                          stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr,
+                                          slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
+                    return rc;
+                HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
+            }
+            return GSW_OK;
+        };
+        const int rc = pipeline();
+        if (rc != GSW_OK) join_aux(ctx);
+        return rc;
     }
     // one stream, workspace-sized chunks
     size_t chunk = ctx->ws_limit / prep;
@@ -839,6 +908,12 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         if (g.op > GSW_GATE_MULT_CONST) return fail(GSW_E_INVALID, "gate %zu: unknown op %u", i, g.op);
         if (g.a >= n_slots || g.out >= n_slots || (g.op != GSW_GATE_MULT_CONST && g.b >= n_slots))
             return fail(GSW_E_INVALID, "gate %zu: slot out of range (pool has %u)", i, n_slots);
+        // every gate is checked here, before the first launch: a rejected list leaves the pool untouched
+        if (g.op == GSW_GATE_MULT_CONST &&
+            (ctx->ring.kind == gswk::kRingFp ? g.b >= gswk::kFpP : (g.b & ~ctx->ring.mask) != 0))
+            return fail(GSW_E_INVALID, "gate %zu: constant %u is not a canonical ring element", i, g.b);
+        if ((g.op == GSW_GATE_MULT || g.op == GSW_GATE_NAND) && (g.out == g.a || g.out == g.b))
+            return fail(GSW_E_INVALID, "gate %zu: a product cannot overwrite its own operand (slot %u)", i, g.out);
     }
     if (int rc = use_device(ctx)) return rc;
 
@@ -870,8 +945,6 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
             ++run_id;
             open = true;
         }
-        if (g.out == g.a || g.out == g.b)
-            return fail(GSW_E_INVALID, "gate %zu: a product cannot overwrite its own operand (slot %u)", i, g.out);
         lhs.push_back(g.a);
         rhs.push_back(g.b);
         out.push_back(g.out);
@@ -911,8 +984,6 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
             if (g.op == GSW_GATE_ADD) {
                 HIP_TRY(gswk::launch_add(ctx->ring, a, d_pool + (size_t)g.b * slot_stride, dst, elems, ctx->stream));
             } else {
-                if (ctx->ring.kind == gswk::kRingFp ? g.b >= gswk::kFpP : (g.b & ~ctx->ring.mask) != 0)
-                    return fail(GSW_E_INVALID, "gate %zu: constant %u is not a canonical ring element", r.gate, g.b);
                 if (dst != a)
                     HIP_TRY(hipMemcpyAsync(dst, a, elems * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
                 HIP_TRY(gswk::launch_mult_const(ctx->ring, dst, g.b, elems, ctx->stream));
@@ -938,33 +1009,27 @@ int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepare
     if (int rc = use_device(ctx)) return rc;
     // stage pk_matrix (m x (n+1), pk.rs:28-38) on the device with the padded leading dimension
     const size_t bytes = (size_t)ctx->m * ctx->ld * 4;
-    uint32_t *tmp = nullptr;
-    HIP_TRY(hipMalloc((void **)&tmp, bytes + 16));
-    hipError_t e = hipMemsetAsync(tmp, 0, bytes, ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(tmp, (size_t)ctx->ld * 4, h_pk_matrix, (size_t)ctx->width * 4, (size_t)ctx->width * 4,
-                             (size_t)ctx->m, hipMemcpyHostToDevice, ctx->stream);
-    int rc = GSW_OK;
-    if (e == hipSuccess) {
-        gswk::PrepArgs a{};
-        a.src = tmp;
-        a.src_stride = 0;
-        a.dst = (uint8_t *)d_pk_prepared;
-        a.dst_stride = gsw_ctx_pk_prepared_bytes(ctx);
-        a.rows_valid = ctx->m;
-        a.cols_valid = ctx->width;
-        a.ld_src = ctx->ld;
-        a.elems = ctx->words;
-        a.e4 = ctx->ld_r;
-        a.batch = 1;
-        a.packed_tail = ctx->packed_tail;
-        a.layout16 = ctx->gemm_variant >= 4;
-        rc = run_prepare(ctx, a, ctx->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    HIP_TRY(e);
-    return rc;
+    if (int rc = ensure_small(ctx, bytes + 16)) return rc;
+    uint32_t *tmp = (uint32_t *)ctx->small;
+    HIP_TRY(hipMemsetAsync(tmp, 0, bytes, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(tmp, (size_t)ctx->ld * 4, h_pk_matrix, (size_t)ctx->width * 4, (size_t)ctx->width * 4,
+                             (size_t)ctx->m, hipMemcpyHostToDevice, ctx->stream));
+    gswk::PrepArgs a{};
+    a.src = tmp;
+    a.src_stride = 0;
+    a.dst = (uint8_t *)d_pk_prepared;
+    a.dst_stride = gsw_ctx_pk_prepared_bytes(ctx);
+    a.rows_valid = ctx->m;
+    a.cols_valid = ctx->width;
+    a.ld_src = ctx->ld;
+    a.elems = ctx->words;
+    a.e4 = ctx->ld_r;
+    a.batch = 1;
+    a.packed_tail = ctx->packed_tail;
+    a.layout16 = ctx->gemm_variant >= 4;
+    if (int rc = run_prepare(ctx, a, ctx->stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's host matrix is free again
+    return GSW_OK;
 }
 GSW_CATCH
 
@@ -1027,18 +1092,14 @@ static int row_dots(gsw_ctx *ctx, const uint32_t *h_vec, int cols, const uint32_
                     int row0, int nrows, int batch, std::vector<uint32_t> &host_out) {
     const size_t vec_bytes = ((size_t)cols * 4 + 255) & ~(size_t)255;
     const size_t out_bytes = (size_t)batch * nrows * 4;
-    uint8_t *tmp = nullptr;
-    HIP_TRY(hipMalloc((void **)&tmp, vec_bytes + out_bytes + 16));
+    if (int rc = ensure_small(ctx, vec_bytes + out_bytes + 16)) return rc;
+    uint8_t *tmp = (uint8_t *)ctx->small;
     host_out.resize((size_t)batch * nrows);
-    hipError_t e = hipMemcpyAsync(tmp, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-        e = gswk::launch_row_dot(ctx->ring, d_x, stride, ld, cols, row0, nrows, (const uint32_t *)tmp, batch,
-                                 (uint32_t *)(tmp + vec_bytes), ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(host_out.data(), tmp + vec_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    HIP_TRY(e);
+    HIP_TRY(hipMemcpyAsync(tmp, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(gswk::launch_row_dot(ctx->ring, d_x, stride, ld, cols, row0, nrows, (const uint32_t *)tmp, batch,
+                                 (uint32_t *)(tmp + vec_bytes), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(host_out.data(), tmp + vec_bytes, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return GSW_OK;
 }
 
@@ -1121,17 +1182,15 @@ int gsw_matvec(gsw_ctx *ctx, const uint32_t *d_mat, int rows, int cols, int ld, 
     if (!ctx || !d_mat || !h_vec || !d_out || rows < 0 || cols < 1 || ld < cols) return fail(GSW_E_INVALID, "bad argument");
     if (rows == 0) return GSW_OK;
     if (int rc = use_device(ctx)) return rc;
-    uint32_t *d_vec = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_vec, (size_t)cols * 4 + 16));
-    hipError_t e = hipMemcpyAsync(d_vec, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream);
-    // the grid's x dimension carries the rows in slabs of at most 65535
-    for (int r0 = 0; e == hipSuccess && r0 < rows; r0 += 32768) {
+    if (int rc = ensure_small(ctx, (size_t)cols * 4 + 16)) return rc;
+    uint32_t *d_vec = (uint32_t *)ctx->small;
+    HIP_TRY(hipMemcpyAsync(d_vec, h_vec, (size_t)cols * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the grid's x dimension carries the rows in slabs
+    for (int r0 = 0; r0 < rows; r0 += 32768) {
         const int cur = rows - r0 < 32768 ? rows - r0 : 32768;
-        e = gswk::launch_row_dot(ctx->ring, d_mat, 0, ld, cols, r0, cur, d_vec, 1, d_out + r0, ctx->stream);
+        HIP_TRY(gswk::launch_row_dot(ctx->ring, d_mat, 0, ld, cols, r0, cur, d_vec, 1, d_out + r0, ctx->stream));
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_vec);
-    HIP_TRY(e);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's host vector is free again
     return GSW_OK;
 }
 
@@ -1168,14 +1227,11 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
     std::vector<uint64_t> cum;
     int kmax = 0;
     gaussian_table(sigma, cum, kmax);
-    uint64_t *d_cum = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_cum, cum.size() * 8));
-    hipError_t e = hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess)
-        e = gswk::launch_sample_table(ctx->ring, seed, stream, d_cum, (int)cum.size(), kmax, d_out, count, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_cum);
-    HIP_TRY(e);
+    if (int rc = ensure_small(ctx, cum.size() * 8)) return rc;
+    uint64_t *d_cum = (uint64_t *)ctx->small;
+    HIP_TRY(hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(gswk::launch_sample_table(ctx->ring, seed, stream, d_cum, (int)cum.size(), kmax, d_out, count, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the host table goes out of scope
     return GSW_OK;
 }
 GSW_CATCH

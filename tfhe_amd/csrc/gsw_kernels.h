@@ -108,6 +108,9 @@ hipError_t launch_sample_table(const RingDesc &ring, uint64_t seed, uint64_t str
                                int table_len, int kmax, uint32_t *out, size_t count, hipStream_t stream);
 // counter calibration (see stream_read_kernel)
 hipError_t launch_stream_read(const void *src, size_t bytes, int mode, size_t pitch, hipStream_t stream);
+// *bad = number of non-canonical or non-zero-padding words over the batch (see validate_kernel)
+hipError_t launch_validate(const RingDesc &ring, const uint32_t *x, size_t stride, int rows, int cols, int ld,
+                           int batch, unsigned long long *bad, hipStream_t stream);
 hipError_t launch_digest(const uint32_t *x, size_t stride, size_t count, int batch, unsigned long long *digests,
                          hipStream_t stream);
 

@@ -369,101 +369,6 @@ constexpr int kPipeBuffers = 3;
 template <int WAVES>
 constexpr int pipe_lds_bytes() { return kPipeBuffers * (WAVES * 1024 + kStageElems * 4 * kFragBytes); }
 
-template <int RING, int WAVES, int NFRAG>
-__device__ __forceinline__ void gemm_pipelined_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
-                                                    unsigned char *smem) {
-    constexpr int kRows = 64 * WAVES;
-    constexpr int kLhs = WAVES * 1024;
-    constexpr int kStage = kLhs + kStageElems * 4 * kFragBytes;  // buffers are sized for NFRAG = 4
-    constexpr int kPieces = kStageElems * NFRAG;                 // 1 KiB pieces of the right operand per stage
-    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
-    constexpr int kLoads = 1 + kRounds;                          // LDS-DMA instructions per wave per stage
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
-
-    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
-    int row_load = mt * kRows + tid;
-    if (row_load > p.rows - 1) row_load = p.rows - 1;  // clamped rows are computed but never stored
-    const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;
-    const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * 64 < p.rows;
-
-    v16i acc[2][NFRAG];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int l = 0; l < NFRAG; ++l)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][l][r] = 0;
-    uint32_t pop0 = 0, pop1 = 0;
-    const int r32 = lane & 31;
-    const int sh = (lane >> 5) * 4;
-
-    auto issue = [&](int t, int buf) {
-        const uint32_t base = lds0 + (uint32_t)(buf * kStage);
-        lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-#pragma unroll
-        for (int j = 0; j < kRounds; ++j) {
-            // when there are fewer pieces than waves the surplus waves re-load a piece (same bytes,
-            // same place), which keeps the per-wave load count uniform for the counted wait
-            const int piece = (j * WAVES + wave) % kPieces;
-            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
-        }
-    };
-
-    issue(0, 0);
-    if (stages > 1) issue(1, 1);
-    // The loop exists twice -- with and without the arithmetic -- so that a wave whose 64 rows lie
-    // beyond the matrix only stages and synchronises; a branch around the MFMAs inside one loop
-    // would make every accumulator a loop-carried merge of two paths.
-    auto main_loop = [&](auto active_tag) {
-        constexpr bool kActive = decltype(active_tag)::value;
-        int buf = 0;
-        for (int t = 0; t < stages; ++t) {
-            // Stage t was issued before stage t+1: once at most kLoads of this wave's loads are
-            // pending, its share of stage t has landed; the barrier extends that to every wave's
-            // share and also tells that all waves are done reading the buffer the next issue
-            // overwrites.
-            if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
-            else wait_vmcnt_then_barrier<0>();
-            if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
-            if constexpr (kActive) {
-                const unsigned char *sa = smem + buf * kStage;
-                const unsigned char *sb = sa + kLhs;
-                const uint4 a0 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + r32) * 16);
-                const uint4 a1 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + 32 + r32) * 16);
-                gemm_kstep<NFRAG>(a0.x, a1.x, sh, sb + 0 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
-                gemm_kstep<NFRAG>(a0.y, a1.y, sh, sb + 1 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
-                gemm_kstep<NFRAG>(a0.z, a1.z, sh, sb + 2 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
-                gemm_kstep<NFRAG>(a0.w, a1.w, sh, sb + 3 * NFRAG * kFragBytes, lane, acc, pop0, pop1);
-            }
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-    };
-    if (wave_active) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-    if (wave_active) {
-        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm_epilogue<RING, NFRAG>(p, c, kRows, acc, pop0, pop1);
-    }
-}
-
-template <int RING, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm_pipelined(GemmArgs p, int ell, uint32_t mask,
-                                                                         int nt_count, int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm_pipelined_body<RING, WAVES, 1>(p, ell, mask, b, nt, mt, smem);
-    else gemm_pipelined_body<RING, WAVES, 4>(p, ell, mask, b, nt, mt, smem);
-}
-
 // ---- the same pipeline on the 16x16x64 MFMA shape.
 //
 // A wave still owns 64 rows x 32 columns x 4 limbs, now as 4 row groups x (2 column groups x 4 limbs)
@@ -559,156 +464,6 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
         }
         if (lane == 0) atomicAdd(&p.digests[c.b], dig * 0x9E3779B97F4A7C15ull);
     }
-}
-
-// ABL is a diagnostic switch (timing-only builds with WRONG results): bit 0 drops the waits and
-// barriers, bit 1 the LDS-DMA issue, bit 2 the left-fragment expansion, bit 3 the right-fragment reads,
-// bit 4 makes every workgroup stage the same (first) tile so that all loads hit in L2, bit 5 drops
-// only the left-operand loads, bit 6 only the right-operand loads.
-template <int RING, int WAVES, bool PACKED, int ABL = 0>
-__device__ __forceinline__ void gemm16_pipelined_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
-                                                      int mt, unsigned char *smem) {
-    constexpr int kRows = 64 * WAVES;
-    constexpr int kLhs = WAVES * 1024;
-    constexpr int kStage = kLhs + kStageElems * 4 * kFragBytes;
-    constexpr int kNB = PACKED ? 2 : 8;                 // right fragments per MFMA step
-    constexpr int kPieces = 2 * kNB;                    // per stage: 2 steps
-    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
-    constexpr int kLoads = 1 + kRounds;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
-
-    const uint32_t *lhs = p.lhs + (size_t)((ABL & 16) ? 0 : b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)((ABL & 16) ? 0 : b) * p.rhs_stride +
-                         (size_t)((ABL & 16) ? 0 : nt) * p.e4 * (4 * kFragBytes);
-    int row_load = ((ABL & 16) ? 0 : mt) * kRows + tid;
-    if (row_load > p.rows - 1) row_load = p.rows - 1;
-    const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;
-    const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * 64 < p.rows;
-
-    v4i acc[4][kNB];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[4] = {0u, 0u, 0u, 0u};
-    const int r16 = lane & 15;
-    const int sh = ((lane >> 4) & 1) * 4;
-    const int word_pair = (lane >> 5) * 8;  // byte offset of this lane's two words in its row's 16 bytes
-
-    auto issue = [&](int t, int buf) {
-        const uint32_t base = lds0 + (uint32_t)(buf * kStage);
-        if constexpr (!(ABL & 32))
-            lds_dma16(a_src + t * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)wave * 1024u));
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        if constexpr (!(ABL & 64)) {
-#pragma unroll
-            for (int j = 0; j < kRounds; ++j) {
-                const int piece = (j * WAVES + wave) % kPieces;
-                lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                          __builtin_amdgcn_readfirstlane(base + (uint32_t)(kLhs + piece * kFragBytes)));
-            }
-        }
-    };
-
-    issue(0, 0);
-    if (stages > 1) issue(1, 1);
-    auto main_loop = [&](auto active_tag) {
-        constexpr bool kActive = decltype(active_tag)::value;
-        int buf = 0;
-        for (int t = 0; t < stages; ++t) {
-            if constexpr (!(ABL & 1)) {
-                if (t + 1 < stages) wait_vmcnt_then_barrier<kLoads>();
-                else wait_vmcnt_then_barrier<0>();
-            }
-            if constexpr (!(ABL & 2)) {
-                if (t + 2 < stages) issue(t + 2, buf == 0 ? 2 : buf - 1);
-            }
-            if constexpr (kActive) {
-                const unsigned char *sa = smem + buf * kStage + wave * 1024 + r16 * 16 + word_pair;
-                const unsigned char *sb = smem + buf * kStage + kLhs + lane * 16;
-                uint2 w[4];
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    w[rg] = *reinterpret_cast<const uint2 *>(sa + rg * 256);
-                    pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
-                }
-                // The right fragments are fetched one group ahead of the MFMAs that use them (two
-                // register sets), so that a wave's LDS latency hides behind its own matrix work.
-                constexpr int kGroup = PACKED ? 2 : 4;            // fragments per group
-                constexpr int kGroups = 2 * kNB / kGroup;         // per stage; fragment index = step * kNB + f
-                v4i fb[2][kGroup];
-                v4i fa[4];
-#pragma unroll
-                for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
-#pragma unroll
-                for (int grp = 0; grp < kGroups; ++grp) {
-                    const int cur = grp & 1;
-                    if (grp + 1 < kGroups) {
-#pragma unroll
-                        for (int j = 0; j < kGroup; ++j) {
-                            if constexpr (ABL & 8) fb[cur ^ 1][j] = fb[cur][j];
-                            else
-                                fb[cur ^ 1][j] =
-                                    *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
-                        }
-                    }
-                    // keep the prefetch above this group's MFMAs (the scheduler would otherwise sink
-                    // every load next to its first use to save registers)
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int step = grp * kGroup / kNB;
-                    const int f0 = grp * kGroup - step * kNB;
-                    if (f0 == 0) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
-                            if constexpr (ABL & 4) {
-                                fa[rg][0] = (int)w[rg].x;
-                                fa[rg][1] = (int)w[rg].y;
-                                fa[rg][2] = (int)w[rg].x;
-                                fa[rg][3] = (int)w[rg].y;
-                            } else {
-                                fa[rg][0] = (int)(y & 0x01010101u);
-                                fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-                                fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-                                fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < kGroup; ++j) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-                            acc[rg][f0 + j] =
-                                __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[cur][j], acc[rg][f0 + j], 0, 0, 0);
-                    }
-                }
-            }
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-    };
-    if (wave_active) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-    if (wave_active) {
-        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
-    }
-}
-
-template <int RING, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_pipelined(GemmArgs p, int ell, uint32_t mask,
-                                                                           int nt_count, int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_pipelined_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
 }
 
 // ---- 16x16x64 pipeline with 64-byte left-operand loads.
@@ -900,16 +655,6 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
         gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
     }
-}
-
-template <int RING, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void binlimb_gemm16_rowblock(GemmArgs p, int ell, uint32_t mask,
-                                                                          int nt_count, int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, WAVES, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_rowblock_body<RING, WAVES, false>(p, ell, mask, b, nt, mt, smem);
 }
 
 // ---- Skewed 256-row pipeline (full column tiles).
@@ -1148,240 +893,12 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     else gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
 }
 
-// ---- Staggered 512-row tile: 8 waves, one workgroup per CU.
-//
-// Waves w and w + 4 share a SIMD.  Between two barriers the early half (waves 0..3) runs both MFMA
-// steps of stage t; the late half (waves 4..7) runs step 1 of stage t - 1, then step 0 of stage t.
-// Each wave's non-MFMA work (left-operand words, fragment expansion) thus falls into the other
-// wave's MFMA time although one barrier per stage keeps all eight in step.  The late half still
-// reads the buffer of stage t - 1 while stage t + 2 is being loaded, hence a four-deep ring.
-
-constexpr int kStaggerRing = 4;
-constexpr int stagger_lds_bytes() { return 2 * 8 * 4096 + kStaggerRing * kStageElems * 4 * kFragBytes; }
-
-template <int RING, bool PACKED>
-__device__ __forceinline__ void gemm16_stagger_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
-                                                    int mt, unsigned char *smem) {
-    constexpr int WAVES = 8;
-    constexpr int kRows = 64 * WAVES;
-    constexpr int kLhsRing = 2 * WAVES * 4096;
-    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
-    constexpr int kNB = PACKED ? 2 : 8;
-    constexpr int kPieces = 2 * kNB;
-    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
-    constexpr int kGroup = PACKED ? 1 : 4;        // fragments per MFMA group
-    constexpr int kHalfGroups = kNB / kGroup;     // groups per MFMA step (2)
-    constexpr int kQuarters = 2 * kHalfGroups;    // groups per stage: the slots the loads are spread over
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
-
-    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
-    const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * 64 < p.rows;
-    const bool late = wave >= 4;
-
-    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
-    const uint32_t *a_row[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
-        if (row > p.rows - 1) row = p.rows - 1;
-        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
-    }
-
-    v4i acc[4][kNB];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[4] = {0u, 0u, 0u, 0u};
-    const int r16 = lane & 15;
-    const int sh = ((lane >> 4) & 1) * 4;
-    const int swz = (r16 >> 2) & 3;
-    const int word_pair = (lane >> 5) * 8;
-
-    auto issue_lhs_piece = [&](int super_stage, int rg) {
-        int st = super_stage * 4 + ld_j;
-        if (st > stages - 1) st = stages - 1;
-        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
-        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
-    };
-    auto issue_rhs_round = [&](int t, int j) {
-        const int buf = t & (kStaggerRing - 1);
-        if (t > stages - 1) t = stages - 1;
-        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        const int piece = (j * WAVES + wave) % kPieces;
-        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
-    };
-    // the loads of the epoch that opens stage t, cut into kQuarters portions
-    auto issue_quarter = [&](int t, bool opens_super_stage, int q) {
-        constexpr int kLhsPer = 4 / kQuarters > 0 ? 4 / kQuarters : 1;
-        if (opens_super_stage) {
-#pragma unroll
-            for (int k = 0; k < kLhsPer; ++k)
-                if (q * kLhsPer + k < 4) issue_lhs_piece((t >> 2) + 1, q * kLhsPer + k);
-        }
-        if (q < kRounds) issue_rhs_round(t + 2, q);
-    };
-
-    // one MFMA step (half a stage): fragments [0, kNB) of `step` in the buffer of stage t_data, the
-    // left-operand word of that step per row group, and the load portions q0, q0 + 1, ..
-    auto mfma_step = [&](int step, int t_data, const uint32_t (&word)[4], int t_epoch, bool opens, int q0) {
-        const unsigned char *sb = smem + kLhsRing + (t_data & (kStaggerRing - 1)) * kRhsStage + lane * 16 +
-                                  step * kNB * kFragBytes;
-        v4i fb[2][kGroup];
-        v4i fa[4];
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const uint32_t y = word[rg] >> sh;
-            fa[rg][0] = (int)(y & 0x01010101u);
-            fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-            fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-            fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-        }
-#pragma unroll
-        for (int grp = 0; grp < kHalfGroups; ++grp) {
-            const int cur = grp & 1;
-            if (grp + 1 < kHalfGroups) {
-#pragma unroll
-                for (int j = 0; j < kGroup; ++j)
-                    fb[cur ^ 1][j] = *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            issue_quarter(t_epoch, opens, q0 + grp);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < kGroup; ++j) {
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    acc[rg][grp * kGroup + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(
-                        fa[rg], fb[cur][j], acc[rg][grp * kGroup + j], 0, 0, 0);
-            }
-        }
-    };
-    auto read_words = [&](int t, uint32_t (&wx)[4], uint32_t (&wy)[4]) {
-        const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
-                                              (((t & 3) ^ swz) * 16) + word_pair);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const uint2 w = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
-            wx[rg] = w.x;
-            wy[rg] = w.y;
-            pop[rg] += __popc(w.x) + __popc(w.y);
-        }
-    };
-
-    // prologue: left operand of super-stage 0, right operand of stages 0 and 1
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(0, j);
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, j);
-
-    uint32_t carry[4] = {0u, 0u, 0u, 0u};  // late half: the step-1 words of the previous stage
-    auto epoch = [&](auto slot_tag, auto mode_tag, int t) {
-        constexpr int kSlot = decltype(slot_tag)::value;  // t mod 4
-        constexpr int kMode = decltype(mode_tag)::value;  // 0 inactive, 1 early, 2 late
-        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
-        const bool opens = kSlot == 0;
-        if constexpr (kMode == 0) {
-#pragma unroll
-            for (int q = 0; q < kQuarters; ++q) issue_quarter(t, opens, q);
-        } else if constexpr (kMode == 1) {
-            uint32_t wx[4], wy[4];
-            read_words(t, wx, wy);
-            mfma_step(0, t, wx, t, opens, 0);
-            mfma_step(1, t, wy, t, opens, kHalfGroups);
-        } else {
-            if constexpr (kMode == 2) {
-                mfma_step(1, t - 1, carry, t, opens, 0);
-            } else {  // mode 3: the late half's first epoch has no previous stage to finish
-#pragma unroll
-                for (int q = 0; q < kHalfGroups; ++q) issue_quarter(t, opens, q);
-            }
-            uint32_t wx[4];
-            read_words(t, wx, carry);
-            mfma_step(0, t, wx, t, opens, kHalfGroups);
-        }
-    };
-    // the first epoch is peeled so that the late half's loop body is free of conditions around MFMAs
-    auto main_loop = [&](auto first_tag, auto mode_tag) {
-        epoch(std::integral_constant<int, 0>{}, first_tag, 0);
-        if (1 < stages) epoch(std::integral_constant<int, 1>{}, mode_tag, 1);
-        if (2 < stages) epoch(std::integral_constant<int, 2>{}, mode_tag, 2);
-        if (3 < stages) epoch(std::integral_constant<int, 3>{}, mode_tag, 3);
-        for (int t0 = 4; t0 < stages; t0 += 4) {
-            epoch(std::integral_constant<int, 0>{}, mode_tag, t0);
-            if (t0 + 1 < stages) epoch(std::integral_constant<int, 1>{}, mode_tag, t0 + 1);
-            if (t0 + 2 < stages) epoch(std::integral_constant<int, 2>{}, mode_tag, t0 + 2);
-            if (t0 + 3 < stages) epoch(std::integral_constant<int, 3>{}, mode_tag, t0 + 3);
-        }
-    };
-    if (!wave_active) main_loop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    else if (!late) main_loop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-    else main_loop(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave_active) {
-        if (late) {
-            // the last stage's second step: its buffer is not a target of the clamped re-loads
-            const unsigned char *sb = smem + kLhsRing + ((stages - 1) & (kStaggerRing - 1)) * kRhsStage + lane * 16 +
-                                      kNB * kFragBytes;
-            v4i fa[4];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const uint32_t y = carry[rg] >> sh;
-                fa[rg][0] = (int)(y & 0x01010101u);
-                fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-                fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-                fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-            }
-#pragma unroll
-            for (int f = 0; f < kNB; ++f) {
-                const v4i fbv = *reinterpret_cast<const v4i *>(sb + f * kFragBytes);
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    acc[rg][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fbv, acc[rg][f], 0, 0, 0);
-            }
-        }
-        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
-    }
-}
-
-template <int RING>
-__global__ __launch_bounds__(512, 1) void binlimb_gemm16_stagger(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                                 int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_stagger_body<RING, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_stagger_body<RING, false>(p, ell, mask, b, nt, mt, smem);
-}
-
-// Timing-only diagnostic builds of the 16x16x64 pipeline (Fp, 4 waves): results are WRONG by design, so
-// they exist only in libraries compiled with -DGSW_DIAGNOSTIC_BUILDS (never the shipped one).
+// Superseded contraction kernels (variants 0, 1, 4..8) and timing-only ablation builds: compiled only into
+// libraries built with -DGSW_DIAGNOSTIC_BUILDS, for A/B timing.  The shipped library holds the default
+// kernel (variant 9) and the simple kernel below (variants 2, 3) as an independent cross-check.
 #ifdef GSW_DIAGNOSTIC_BUILDS
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void binlimb_gemm16_ablate(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                                 int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_pipelined_body<kRingFp, 4, true, ABL>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_pipelined_body<kRingFp, 4, false, ABL>(p, ell, mask, b, nt, mt, smem);
-}
-#endif  // GSW_DIAGNOSTIC_BUILDS
+#include "gsw_kernels_diag.inc"
+#endif
 
 // Counter calibration: streams `bytes` (a multiple of 64 KiB) once through the same LDS-DMA instruction
 // the contraction uses, 1 KiB per wave instruction (mode 0) or 16 rows x 64 B at `pitch` bytes (mode 1),
@@ -1505,13 +1022,16 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
     }
 #endif
     if (variant < 0 || variant > 9) return hipErrorInvalidValue;
+#ifndef GSW_DIAGNOSTIC_BUILDS
+    if (variant != 2 && variant != 3 && variant != 9) return hipErrorInvalidValue;  // not in the shipped library
+#endif
     if (a.packed_tail && (variant == 2 || variant == 3)) return hipErrorInvalidValue;  // no packed tile there
     const int tile_rows = (variant == 1 || variant == 5 || variant == 7 || variant == 8) ? 512 : 256;
     const int nt = col_tiles(a.out_cols);
     const int mt = (a.rows + tile_rows - 1) / tile_rows;
     const long units = (long)a.batch * nt;
     const long groups = (units + 7) / 8;
-    // variants 4..7 place whole batch entries per XCD (map_workgroup_blocked), the others column tiles
+    // variants 4..9 place whole batch entries per XCD (map_workgroup_blocked), the others column tiles
     const long blocks = variant >= 4 ? (((long)a.batch + 7) / 8) * 8 * nt * mt : groups * 8 * mt;
     if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks);
@@ -1519,14 +1039,6 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
 #define GSW_LAUNCH(KERNEL, THREADS, LDS) \
     hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), LDS, stream, a, ring.ell, ring.mask, nt, mt)
     switch (variant) {
-        case 0:
-            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
-            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 4>), 256, pipe_lds_bytes<4>());
-            break;
-        case 1:
-            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 8>), 512, pipe_lds_bytes<8>());
-            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 8>), 512, pipe_lds_bytes<8>());
-            break;
         case 2:
             if (fp) GSW_LAUNCH((binlimb_gemm_kernel<kRingFp, true>), 256, kGemmLds);
             else GSW_LAUNCH((binlimb_gemm_kernel<kRingZpow2, true>), 256, kGemmLds);
@@ -1534,6 +1046,15 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
         case 3:
             if (fp) GSW_LAUNCH((binlimb_gemm_kernel<kRingFp, false>), 256, kGemmLds);
             else GSW_LAUNCH((binlimb_gemm_kernel<kRingZpow2, false>), 256, kGemmLds);
+            break;
+#ifdef GSW_DIAGNOSTIC_BUILDS
+        case 0:
+            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
+            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 4>), 256, pipe_lds_bytes<4>());
+            break;
+        case 1:
+            if (fp) GSW_LAUNCH((binlimb_gemm_pipelined<kRingFp, 8>), 512, pipe_lds_bytes<8>());
+            else GSW_LAUNCH((binlimb_gemm_pipelined<kRingZpow2, 8>), 512, pipe_lds_bytes<8>());
             break;
         case 4:
             if (fp) GSW_LAUNCH((binlimb_gemm16_pipelined<kRingFp, 4>), 256, pipe_lds_bytes<4>());
@@ -1555,6 +1076,7 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
             if (fp) GSW_LAUNCH((binlimb_gemm16_stagger<kRingFp>), 512, stagger_lds_bytes());
             else GSW_LAUNCH((binlimb_gemm16_stagger<kRingZpow2>), 512, stagger_lds_bytes());
             break;
+#endif
         default:
             if (fp) GSW_LAUNCH((binlimb_gemm16_skew<kRingFp>), 256, rowblock_lds_bytes<4>());
             else GSW_LAUNCH((binlimb_gemm16_skew<kRingZpow2>), 256, rowblock_lds_bytes<4>());
@@ -1747,14 +1269,22 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const uint32_t *x, size_t 
 hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride, int ld, int cols, int row0,
                           int nrows, const uint32_t *vec, int batch, uint32_t *out, hipStream_t stream) {
     if (batch <= 0 || nrows <= 0) return hipSuccess;
-    dim3 grid((unsigned)nrows, (unsigned)batch), block(256);
-    if (ring.kind == kRingFp)
-        hipLaunchKernelGGL(row_dot_kernel<kRingFp>, grid, block, 0, stream, x, stride, ld, cols, row0, vec, out,
-                           ring.mask);
-    else
-        hipLaunchKernelGGL(row_dot_kernel<kRingZpow2>, grid, block, 0, stream, x, stride, ld, cols, row0, vec, out,
-                           ring.mask);
-    return hipGetLastError();
+    // the batch rides in gridDim.y, which holds at most 65535: longer batches go in slabs
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int cur = batch - b0 < 65535 ? batch - b0 : 65535;
+        dim3 grid((unsigned)nrows, (unsigned)cur), block(256);
+        const uint32_t *xs = x + (size_t)b0 * stride;
+        uint32_t *os = out + (size_t)b0 * nrows;
+        if (ring.kind == kRingFp)
+            hipLaunchKernelGGL(row_dot_kernel<kRingFp>, grid, block, 0, stream, xs, stride, ld, cols, row0, vec, os,
+                               ring.mask);
+        else
+            hipLaunchKernelGGL(row_dot_kernel<kRingZpow2>, grid, block, 0, stream, xs, stride, ld, cols, row0, vec, os,
+                               ring.mask);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------ sampling and digests
@@ -1862,6 +1392,46 @@ __global__ __launch_bounds__(256) void digest_kernel(const uint32_t *x, size_t s
         __syncthreads();
     }
     if (threadIdx.x == 0) atomicAdd(&digests[b], part[0]);
+}
+
+// Counts the words of a batch of rows x ld matrices that break the operand invariants of the contraction:
+// a value that is not canonical (>= p, or a bit at or above M), or a non-zero word in a padding column.
+template <int RING>
+__global__ __launch_bounds__(256) void validate_kernel(const uint32_t *x, size_t stride, int rows, int cols, int ld,
+                                                        uint32_t mask, unsigned long long *bad) {
+    const int b = blockIdx.y;
+    const uint32_t *p = x + (size_t)b * stride;
+    const size_t total = (size_t)rows * ld;
+    unsigned count = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = p[i];
+        const int col = (int)(i % (size_t)ld);
+        if (col >= cols) count += v != 0u;
+        else count += RING == kRingFp ? v >= kFpP : (v & ~mask) != 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) count += (unsigned)__shfl_xor((int)count, off, 64);
+    if ((threadIdx.x & 63) == 0 && count) atomicAdd(bad, (unsigned long long)count);
+}
+
+hipError_t launch_validate(const RingDesc &ring, const uint32_t *x, size_t stride, int rows, int cols, int ld,
+                           int batch, unsigned long long *bad, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess || batch <= 0 || rows <= 0) return e;
+    unsigned gx = (unsigned)(((size_t)rows * ld + 256 * 16 - 1) / (256 * 16));
+    if (gx > 64) gx = 64;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int cur = batch - b0 < 65535 ? batch - b0 : 65535;
+        dim3 grid(gx, (unsigned)cur), block(256);
+        const uint32_t *xs = x + (size_t)b0 * stride;
+        if (ring.kind == kRingFp)
+            hipLaunchKernelGGL(validate_kernel<kRingFp>, grid, block, 0, stream, xs, stride, rows, cols, ld, ring.mask, bad);
+        else
+            hipLaunchKernelGGL(validate_kernel<kRingZpow2>, grid, block, 0, stream, xs, stride, rows, cols, ld, ring.mask, bad);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_digest(const uint32_t *x, size_t stride, size_t count, int batch, unsigned long long *digests,
