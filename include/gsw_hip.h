@@ -136,6 +136,20 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
                                 size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
                                 uint64_t *d_digests);
 
+/* No counterpart in the reference.  gsw_mul_gadget_batch for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the prepared right
+ * operands are staged in a fixed device array of the library, GSW_STATIC_SCRATCH_BYTES per GPU, held from
+ * the library's load to the end of the process, instead of the context's growable workspace.  The call
+ * allocates and frees nothing on the device or through the HIP runtime.  Products go through the array
+ * in chunks of floor(GSW_STATIC_SCRATCH_BYTES / gsw_ctx_prepared_bytes()) on the context's stream, one
+ * after another, so any batch length is accepted; a context whose single prepared operand exceeds the
+ * array (n above 512 for Fp) is refused with GSW_E_UNSUPPORTED.  Kernel timing (gsw_ctx_enable_timing)
+ * does not cover this call.  Every context on a GPU shares that GPU's array: calls that overlap in time
+ * on one GPU (two contexts, two streams, two threads) race on it -- serialise them. */
+#define GSW_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c,
+                                size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags);
+
 /* ---- gate lists over resident ciphertexts: what a caller of mult / nand / add / mult_const
  *      (gsw_impl.rs:87-123) does next -- chains and NAND circuits -- without the operands leaving
  *      HBM.  The pool holds n_slots compact ciphertexts slot_stride uint32 apart. ---- */

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GSW_HIP_LIBRARY") or os.path.join(_HERE, "libgsw_hip.
 RING_FP_M31 = 0
 RING_ZPOW2 = 1
 FLAG_NAND = 1
+STATIC_SCRATCH_BYTES = 64 << 20  # GSW_STATIC_SCRATCH_BYTES
 
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_NOMEM = 0, 1, 2, 3, 4
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
+    "gsw_mul_gadget_batch_static": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),
     "gsw_mul_gadget_batch_digest": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint, _vp]),
     "gsw_eval_circuit": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Gate), _sz]),
     "gsw_prepare_pk": (_i, [_vp, _vp, _vp]),

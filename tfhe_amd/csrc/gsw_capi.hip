@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -47,6 +48,31 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+// Scratch of gsw_mul_gadget_batch_static: the prepared right operands of one chunk.  A file-scope device
+// array: every GPU the library runs on holds its own copy, at its own address, until the process ends.
+// In host code the name is only a handle for hipGetSymbolAddress -- never a device address: host code
+// uses the per-device pointers resolved below.
+__device__ __align__(256) unsigned char g_static_scratch[GSW_STATIC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mutex;
+void *g_static_ptr[kMaxDevices];  // device address of g_static_scratch on each GPU, resolved on first use
+
+// Device address of the scratch array on `device`, which must be the current device.  Called by
+// gsw_ctx_create, the library's set-up call on a device; resolved once per device.
+int resolve_static_scratch(int device, void **out) {
+    if (device < 0 || device >= kMaxDevices) return fail(GSW_E_INVALID, "device %d beyond the %d supported", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_ptr[device]) {
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch)));
+        if (!ptr) return fail(GSW_E_HIP, "hipGetSymbolAddress returned a null address for the static scratch array");
+        g_static_ptr[device] = ptr;
+    }
+    *out = g_static_ptr[device];
+    return GSW_OK;
+}
+
 }  // namespace
 
 struct gsw_ctx {
@@ -68,6 +94,8 @@ struct gsw_ctx {
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
+    void *static_scratch;  // this GPU's copy of the library's static scratch array (gsw_mul_gadget_batch_static)
+    bool in_static_call;   // inside gsw_mul_gadget_batch_static: nothing may allocate, not even timing events
     void *small;         // scratch of the helpers that return values to the host (row dots, tables, staging)
     size_t small_bytes;
     int gemm_variant;
@@ -135,7 +163,7 @@ struct ScopedTimer {
     hipStream_t stream;
     TimedLaunch t{};
     bool on;
-    ScopedTimer(gsw_ctx *c, int w, hipStream_t s) : ctx(c), which(w), stream(s), on(c->timing) {
+    ScopedTimer(gsw_ctx *c, int w, hipStream_t s) : ctx(c), which(w), stream(s), on(c->timing && !c->in_static_call) {
         if (on) {
             if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) on = false;
             else hipEventRecord(t.start, stream);
@@ -301,6 +329,10 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
                                    "superseded kernels exist only in a -DGSW_DIAGNOSTIC_BUILDS library");
     }
     ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
+    if (int rc = resolve_static_scratch(device, &ctx->static_scratch)) {  // `device` is current (hipSetDevice above)
+        delete ctx;
+        return rc;
+    }
     hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming);
@@ -890,6 +922,48 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
                                 uint64_t *d_digests) {
     if (!d_digests) return fail(GSW_E_INVALID, "null digest buffer");
     return mul_batch(ctx, d_c1c, stride1, d_c2c, stride2, d_out, stride_out, batch, flags, d_digests);
+}
+
+// gsw_mul_gadget_batch without device allocation: the prepared operands of a chunk live in this GPU's copy of
+// g_static_scratch (ctx->static_scratch, resolved at gsw_ctx_create), chunks run one after another on
+// ctx->stream.  No hipMalloc / hipFree / event creation on this path; the stream's order protects the
+// scratch between chunks and between successive calls on the same stream.
+int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c,
+                                size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags) {
+    if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
+    if (batch == 0) return GSW_OK;
+    if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
+    const size_t elems = gsw_ctx_compact_elems(ctx);
+    if (int rc = check_no_alias(ctx, d_c1c, stride1, elems, d_out, stride_out, batch, "left")) return rc;
+    if (int rc = check_no_alias(ctx, d_c2c, stride2, elems, d_out, stride_out, batch, "right")) return rc;
+    const size_t prep = gsw_ctx_prepared_bytes(ctx);
+    if (prep > GSW_STATIC_SCRATCH_BYTES)
+        return fail(GSW_E_UNSUPPORTED, "one prepared operand of this context takes %zu bytes, the static scratch holds %zu: "
+                                       "n=%d is beyond what gsw_mul_gadget_batch_static supports", prep,
+                    (size_t)GSW_STATIC_SCRATCH_BYTES, ctx->n);
+    if (!ctx->static_scratch) return fail(GSW_E_HIP, "the static scratch array was not resolved on device %d", ctx->device);
+    if (int rc = use_device(ctx)) return rc;
+    struct Guard {
+        gsw_ctx *c;
+        explicit Guard(gsw_ctx *c_) : c(c_) { c->in_static_call = true; }
+        ~Guard() { c->in_static_call = false; }
+    } guard(ctx);
+    void *scratch = ctx->static_scratch;  // the device address, never the array's name
+    if (stride2 == 0) {
+        // one right operand for the whole batch: prepared once
+        if (int rc = prepare_rhs_on(ctx, d_c2c, 0, scratch, 1, ctx->stream)) return rc;
+        return mul_prepared(ctx, d_c1c, stride1, scratch, 0, d_out, stride_out, batch, flags, nullptr);
+    }
+    size_t chunk = GSW_STATIC_SCRATCH_BYTES / prep;
+    if (chunk > (size_t)batch) chunk = (size_t)batch;
+    for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
+        const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
+        if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, scratch, cur, ctx->stream)) return rc;
+        if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, scratch, prep, d_out + b0 * stride_out,
+                                  stride_out, cur, flags, nullptr))
+            return rc;
+    }
+    return GSW_OK;
 }
 
 // ---- gate lists over a pool of resident ciphertexts ----
