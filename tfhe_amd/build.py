@@ -5,8 +5,10 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(HERE, "csrc", "gsw_kernels.hip"), os.path.join(HERE, "csrc", "gsw_capi.hip")]
-HEADERS = [os.path.join(HERE, "csrc", "gsw_kernels.h"), os.path.join(HERE, "..", "include", "gsw_hip.h")]
+SOURCES = [os.path.join(HERE, "csrc", "gsw_kernels.hip"), os.path.join(HERE, "csrc", "gsw_capi.hip"),
+           os.path.join(HERE, "csrc", "gsw_wire.cpp")]  # gsw_wire.cpp: host-only (wire format parser, sampler table)
+HEADERS = [os.path.join(HERE, "csrc", "gsw_kernels.h"), os.path.join(HERE, "csrc", "gsw_wire.h"),
+           os.path.join(HERE, "..", "include", "gsw_hip.h")]
 # -DGSW_DIAGNOSTIC_BUILDS additionally compiles csrc/gsw_kernels_diag.inc (superseded kernels, for A/B timing)
 OUT = os.path.join(HERE, "libgsw_hip.so")
 

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "gsw_kernels.h"
+#include "gsw_wire.h"
 
 namespace {
 
@@ -227,24 +228,6 @@ int run_prepare(gsw_ctx *ctx, const gswk::PrepArgs &a, hipStream_t stream) {
     ScopedTimer timer(ctx, 1, stream);
     HIP_TRY(gswk::launch_prepare(ctx->ring, a, stream));
     return GSW_OK;
-}
-
-// cumulative table of the discrete Gaussian P(k) ~ exp(-k^2 / (2 sigma^2)), k in [-kmax, kmax]
-void gaussian_table(double sigma, std::vector<uint64_t> &cum, int &kmax) {
-    kmax = (int)std::ceil(13.0 * sigma) + 1;
-    if (kmax > 4096) kmax = 4096;
-    const int len = 2 * kmax + 1;
-    cum.resize(len);
-    long double total = 0.0L;
-    for (int k = -kmax; k <= kmax; ++k) total += expl(-(long double)k * k / (2.0L * sigma * sigma));
-    long double run = 0.0L;
-    for (int idx = 0; idx < len; ++idx) {
-        const int k = idx - kmax;
-        run += expl(-(long double)k * k / (2.0L * sigma * sigma)) / total;
-        const long double scaled = run * 18446744073709551616.0L;
-        cum[idx] = scaled >= 18446744073709551615.0L ? 0xFFFFFFFFFFFFFFFFull : (uint64_t)scaled;
-    }
-    cum[len - 1] = 0xFFFFFFFFFFFFFFFFull;
 }
 
 // streams and events of a context; null handles (never created) are skipped
@@ -506,117 +489,53 @@ int gsw_download_compact(gsw_ctx *ctx, uint32_t *h_dst, const uint32_t *d_src) {
     return GSW_OK;
 }
 
-// ---- wire format ----
+// ---- wire format (the parser and writer are host code of their own: gsw_wire.cpp) ----
 
 namespace {
 
-constexpr size_t kWireHeader = 32, kWireTrailer = 8;
+using gswwire::kHeaderBytes;
 
-struct WireShape {
-    uint32_t rows, cols;
-};
-
-bool wire_shape(const gsw_ctx *ctx, int kind, WireShape &s) {
-    switch (kind) {
-        case GSW_WIRE_CIPHERTEXT: s = {(uint32_t)ctx->big_n, (uint32_t)ctx->width}; return true;
-        case GSW_WIRE_PUBLIC_KEY: s = {(uint32_t)ctx->m, (uint32_t)ctx->width}; return true;
-        case GSW_WIRE_SECRET_KEY: s = {1u, (uint32_t)ctx->n}; return true;
-        default: return false;
-    }
+gswwire::Params wire_params(const gsw_ctx *ctx) {
+    gswwire::Params p{};
+    p.ring_kind = ctx->ring.kind == gswk::kRingFp ? GSW_RING_FP_M31 : GSW_RING_ZPOW2;
+    p.bits = ctx->ring.ell;
+    p.mask = ctx->ring.mask;
+    p.n = ctx->n;
+    p.m = ctx->m;
+    p.big_n = (uint32_t)ctx->big_n;
+    p.width = (uint32_t)ctx->width;
+    return p;
 }
 
-void put_u32(uint8_t *p, uint32_t v) { for (int i = 0; i < 4; ++i) p[i] = (uint8_t)(v >> (8 * i)); }
-uint32_t get_u32(const uint8_t *p) { return p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
-
-// position-weighted digest of gsw_digest_batch over `count` little-endian u32 values
-uint64_t wire_digest(const uint8_t *payload, size_t count) {
-    uint64_t acc = 0;
-    for (size_t i = 0; i < count; ++i) acc += ((uint64_t)get_u32(payload + 4 * i) + 1) * (2 * (uint64_t)i + 1);
-    return acc * 0x9E3779B97F4A7C15ull;
-}
-
-void wire_header(const gsw_ctx *ctx, int kind, const WireShape &sh, uint32_t count, uint8_t *h) {
-    memset(h, 0, kWireHeader);
-    memcpy(h, "GSW1", 4);
-    h[4] = (uint8_t)kind;
-    h[5] = (uint8_t)(ctx->ring.kind == gswk::kRingFp ? GSW_RING_FP_M31 : GSW_RING_ZPOW2);
-    h[6] = (uint8_t)ctx->ring.ell;
-    put_u32(h + 8, (uint32_t)ctx->n);
-    put_u32(h + 12, (uint32_t)ctx->m);
-    put_u32(h + 16, sh.rows);
-    put_u32(h + 20, sh.cols);
-    put_u32(h + 24, count);
-}
-
-void wire_trailer(uint8_t *buf, size_t elems) {
-    const uint64_t d = wire_digest(buf + kWireHeader, elems);
-    for (int i = 0; i < 8; ++i) buf[kWireHeader + 4 * elems + i] = (uint8_t)(d >> (8 * i));
-}
-
-// validates everything but the payload's placement; returns the entry count through *count
 int wire_check(const gsw_ctx *ctx, int kind, const uint8_t *buf, size_t bytes, uint32_t *count) {
-    WireShape sh{};
-    if (!wire_shape(ctx, kind, sh)) return fail(GSW_E_INVALID, "unknown wire object kind %d", kind);
-    if (bytes < kWireHeader + kWireTrailer) return fail(GSW_E_INVALID, "wire object truncated (%zu bytes)", bytes);
-    if (memcmp(buf, "GSW1", 4) != 0) return fail(GSW_E_INVALID, "bad magic: not a GSW1 wire object");
-    if (buf[4] != kind) return fail(GSW_E_INVALID, "wire object holds kind %d, expected %d", buf[4], kind);
-    const int ring_kind = ctx->ring.kind == gswk::kRingFp ? GSW_RING_FP_M31 : GSW_RING_ZPOW2;
-    if (buf[5] != ring_kind || buf[6] != ctx->ring.ell)
-        return fail(GSW_E_INVALID, "wire object is over ring (%d, %d bits), context over (%d, %d bits)", buf[5], buf[6],
-                    ring_kind, ctx->ring.ell);
-    if (buf[7] != 0 || get_u32(buf + 28) != 0) return fail(GSW_E_INVALID, "reserved header bytes are not zero");
-    if (get_u32(buf + 8) != (uint32_t)ctx->n || get_u32(buf + 12) != (uint32_t)ctx->m)
-        return fail(GSW_E_INVALID, "wire object has (n, m) = (%u, %u), context (%d, %d)", get_u32(buf + 8),
-                    get_u32(buf + 12), ctx->n, ctx->m);
-    if (get_u32(buf + 16) != sh.rows || get_u32(buf + 20) != sh.cols)
-        return fail(GSW_E_INVALID, "wire object is %u x %u, expected %u x %u", get_u32(buf + 16), get_u32(buf + 20),
-                    sh.rows, sh.cols);
-    const uint32_t cnt = get_u32(buf + 24);
-    if (kind != GSW_WIRE_CIPHERTEXT && cnt != 1) return fail(GSW_E_INVALID, "a key object holds exactly one entry");
-    // the count is untrusted: bound it by the bytes at hand before multiplying
-    const size_t per_entry = (size_t)sh.rows * sh.cols;
-    if (per_entry == 0 || cnt > (bytes - kWireHeader - kWireTrailer) / 4 / per_entry)
-        return fail(GSW_E_INVALID, "wire object is %zu bytes, too short for the %u entries its header names", bytes, cnt);
-    const size_t elems = (size_t)cnt * per_entry;
-    if (bytes != kWireHeader + 4 * elems + kWireTrailer)
-        return fail(GSW_E_INVALID, "wire object is %zu bytes, its header implies %zu", bytes,
-                    kWireHeader + 4 * elems + kWireTrailer);
-    const uint8_t *payload = buf + kWireHeader;
-    for (size_t i = 0; i < elems; ++i) {
-        const uint32_t v = get_u32(payload + 4 * i);
-        if (ctx->ring.kind == gswk::kRingFp ? v >= gswk::kFpP : (v & ~ctx->ring.mask) != 0)
-            return fail(GSW_E_INVALID, "element %zu (%u) is not a canonical ring value", i, v);
-    }
-    uint64_t d = 0;
-    for (int i = 0; i < 8; ++i) d |= (uint64_t)payload[4 * elems + i] << (8 * i);
-    if (d != wire_digest(payload, elems)) return fail(GSW_E_INVALID, "digest mismatch: wire object corrupted");
-    *count = cnt;
+    std::string err;
+    if (!gswwire::check(wire_params(ctx), kind, buf, bytes, count, err)) return fail(GSW_E_INVALID, "%s", err.c_str());
     return GSW_OK;
 }
 
 }  // namespace
 
 size_t gsw_wire_bytes(const gsw_ctx *ctx, int kind, int count) {
-    WireShape sh{};
-    if (!ctx || count < 0 || !wire_shape(ctx, kind, sh)) return 0;
-    return kWireHeader + 4 * (size_t)count * sh.rows * sh.cols + kWireTrailer;
+    if (!ctx || count < 0) return 0;
+    return gswwire::object_bytes(wire_params(ctx), kind, (size_t)count);
 }
 
 int gsw_wire_write_host(gsw_ctx *ctx, int kind, const uint32_t *h_values, void *h_out, size_t out_bytes) {
-    WireShape sh{};
+    gswwire::Shape sh{};
     if (!ctx || !h_values || !h_out) return fail(GSW_E_INVALID, "bad argument");
-    if ((kind != GSW_WIRE_PUBLIC_KEY && kind != GSW_WIRE_SECRET_KEY) || !wire_shape(ctx, kind, sh))
+    const gswwire::Params wp = wire_params(ctx);
+    if ((kind != GSW_WIRE_PUBLIC_KEY && kind != GSW_WIRE_SECRET_KEY) || !gswwire::shape_of(wp, kind, sh))
         return fail(GSW_E_INVALID, "kind %d is not a host-resident object", kind);
     if (out_bytes != gsw_wire_bytes(ctx, kind, 1)) return fail(GSW_E_INVALID, "output buffer must be %zu bytes", gsw_wire_bytes(ctx, kind, 1));
     uint8_t *buf = (uint8_t *)h_out;
     const size_t elems = (size_t)sh.rows * sh.cols;
-    wire_header(ctx, kind, sh, 1, buf);
+    gswwire::write_header(wp, kind, sh, 1, buf);
     for (size_t i = 0; i < elems; ++i) {
-        if (ctx->ring.kind == gswk::kRingFp ? h_values[i] >= gswk::kFpP : (h_values[i] & ~ctx->ring.mask) != 0)
+        if (!gswwire::canonical(wp, h_values[i]))
             return fail(GSW_E_INVALID, "element %zu (%u) is not a canonical ring value", i, h_values[i]);
-        put_u32(buf + kWireHeader + 4 * i, h_values[i]);
+        gswwire::put_u32(buf + kHeaderBytes + 4 * i, h_values[i]);
     }
-    wire_trailer(buf, elems);
+    gswwire::write_trailer(buf, elems);
     return GSW_OK;
 }
 
@@ -626,10 +545,10 @@ int gsw_wire_read_host(gsw_ctx *ctx, int kind, const void *h_in, size_t in_bytes
         return fail(GSW_E_INVALID, "kind %d is not a host-resident object", kind);
     uint32_t count = 0;
     if (int rc = wire_check(ctx, kind, (const uint8_t *)h_in, in_bytes, &count)) return rc;
-    WireShape sh{};
-    wire_shape(ctx, kind, sh);
-    const uint8_t *payload = (const uint8_t *)h_in + kWireHeader;
-    for (size_t i = 0; i < (size_t)sh.rows * sh.cols; ++i) h_values[i] = get_u32(payload + 4 * i);
+    gswwire::Shape sh{};
+    gswwire::shape_of(wire_params(ctx), kind, sh);
+    const uint8_t *payload = (const uint8_t *)h_in + kHeaderBytes;
+    for (size_t i = 0; i < (size_t)sh.rows * sh.cols; ++i) h_values[i] = gswwire::get_u32(payload + 4 * i);
     return GSW_OK;
 }
 
@@ -640,18 +559,19 @@ int gsw_wire_write_compact(gsw_ctx *ctx, const uint32_t *d_cc, size_t stride, in
     if (out_bytes != gsw_wire_bytes(ctx, GSW_WIRE_CIPHERTEXT, batch))
         return fail(GSW_E_INVALID, "output buffer must be %zu bytes", gsw_wire_bytes(ctx, GSW_WIRE_CIPHERTEXT, batch));
     if (int rc = use_device(ctx)) return rc;
-    WireShape sh{};
-    wire_shape(ctx, GSW_WIRE_CIPHERTEXT, sh);
+    gswwire::Shape sh{};
+    const gswwire::Params wp = wire_params(ctx);
+    gswwire::shape_of(wp, GSW_WIRE_CIPHERTEXT, sh);
     uint8_t *buf = (uint8_t *)h_out;
-    wire_header(ctx, GSW_WIRE_CIPHERTEXT, sh, (uint32_t)batch, buf);
+    gswwire::write_header(wp, GSW_WIRE_CIPHERTEXT, sh, (uint32_t)batch, buf);
     const size_t per = (size_t)sh.rows * sh.cols;
     // the payload is little-endian u32, which is the host's own representation on every ROCm platform
     for (int b = 0; b < batch; ++b)
-        HIP_TRY(hipMemcpy2DAsync(buf + kWireHeader + 4 * per * b, (size_t)ctx->width * 4, d_cc + (size_t)b * stride,
+        HIP_TRY(hipMemcpy2DAsync(buf + kHeaderBytes + 4 * per * b, (size_t)ctx->width * 4, d_cc + (size_t)b * stride,
                                  (size_t)ctx->ld * 4, (size_t)ctx->width * 4, (size_t)ctx->big_n,
                                  hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    wire_trailer(buf, per * batch);
+    gswwire::write_trailer(buf, per * batch);
     return GSW_OK;
 }
 
@@ -666,7 +586,7 @@ int gsw_wire_read_compact(gsw_ctx *ctx, const void *h_in, size_t in_bytes, uint3
     if (stride < gsw_ctx_compact_elems(ctx) && count > 1) return fail(GSW_E_INVALID, "stride smaller than one ciphertext");
     if (int rc = use_device(ctx)) return rc;
     const size_t per = (size_t)ctx->big_n * ctx->width;
-    const uint8_t *payload = (const uint8_t *)h_in + kWireHeader;
+    const uint8_t *payload = (const uint8_t *)h_in + kHeaderBytes;
     for (uint32_t b = 0; b < count; ++b) {
         uint32_t *dst = d_cc + (size_t)b * stride;
         HIP_TRY(hipMemsetAsync(dst, 0, gsw_ctx_compact_elems(ctx) * 4, ctx->stream));
@@ -1300,7 +1220,7 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
     if (int rc = use_device(ctx)) return rc;
     std::vector<uint64_t> cum;
     int kmax = 0;
-    gaussian_table(sigma, cum, kmax);
+    gswwire::gaussian_table(sigma, cum, kmax);
     if (int rc = ensure_small(ctx, cum.size() * 8)) return rc;
     uint64_t *d_cum = (uint64_t *)ctx->small;
     HIP_TRY(hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, ctx->stream));
