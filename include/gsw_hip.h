@@ -93,6 +93,15 @@ int gsw_download_compact(gsw_ctx *ctx, uint32_t *h_dst, const uint32_t *d_src);
 /* ---- gadget helpers (gsw/helper.rs) ---- */
 /* bit_decomp_matrix (helper.rs:7-21): d_in rows x cols (leading dim ld_in) -> d_out rows x cols*ell, tight */
 int gsw_bit_decomp(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, uint32_t *d_out);
+/* The same decomposition in the format its consumer reads (helper.rs:7-21 fixes the bit order, not the storage):
+ * GSW_DECOMP_U32 as above; GSW_DECOMP_U8 one byte per bit (rows of cols*ell bytes); GSW_DECOMP_BITS the row's
+ * cols*ell bits as one little-endian bit string, 32 per uint32, rows of ceil(cols*ell / 32) words.
+ * gsw_bit_decomp_row_elems gives the elements (uint32 / bytes / words) of one output row; rows are tight. */
+#define GSW_DECOMP_U32 0
+#define GSW_DECOMP_U8 1
+#define GSW_DECOMP_BITS 2
+size_t gsw_bit_decomp_row_elems(const gsw_ctx *ctx, int cols, int format);
+int gsw_bit_decomp_as(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, void *d_out, int format);
 /* bit_decomp_inv_matrix (helper.rs:24-49): d_in rows x cols*ell tight -> d_out rows x cols (leading dim ld_out).
  * quirk != 0 reproduces the reference (bit set iff entry == 1, then R::from); quirk == 0 is the linear inverse. */
 int gsw_bit_decomp_inv(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, uint32_t *d_out, int ld_out,
@@ -105,10 +114,20 @@ int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols);
  * also valid on compact ciphertexts (count = gsw_ctx_compact_elems) */
 int gsw_add(gsw_ctx *ctx, const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_out, size_t count);
 int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t count);
-/* mult (gsw_impl.rs:104-111, default features) and nand (gsw_impl.rs:114-123): the plain
- * dim x dim x dim product over R for arbitrary entries.  Parity path, not the throughput path. */
+/* mult (gsw_impl.rs:104-111, default features) and nand (gsw_impl.rs:114-123): the dim x dim x dim product
+ * over R for arbitrary entries.  When dim is the context's N and the left operand has the reference's own
+ * ciphertext format -- BitDecomp(R * A) + mu * I (gsw_impl.rs:27-42): entries 0 / 1 everywhere off the
+ * diagonal -- the product runs as B * C2 + diag(d) * C2 on the int8-MFMA contraction (B the binary part, d the
+ * diagonal entries other than 0 / 1); any other operand takes the plain dim^3 kernel.  The form is detected
+ * on the device (one pass over C1 and a host synchronisation per call); results are identical. */
 int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
 int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
+/* 0: every dense product on the plain kernel (A/B timing, cross-checks); 1 (default): the MFMA path from
+ * 1024 rows up, where it pays (N = 341: 0.06 ms against 0.02 ms plain; N = 7967: 3.2 ms against 78 ms);
+ * 2: the MFMA path whenever the left operand has the form */
+int gsw_ctx_set_dense_fast(gsw_ctx *ctx, int enable);
+/* which kernel the last dense product of this context used: 0 = plain dim^3, 1 = MFMA contraction */
+int gsw_ctx_last_dense_path(const gsw_ctx *ctx);
 
 /* ---- the hot path: Pc = G^-1(C1c) * C2c mod q on int8 MFMA (gsw_impl.rs:104-123 via the
  *      identity above).  Strides are in uint32 elements between consecutive batch entries;

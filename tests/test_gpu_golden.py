@@ -42,8 +42,15 @@ def test_engine_matches_golden(path):
         assert gsw.decrypt(sk, nand) == 1 - int(g["decrypt_mul"][0])
     if "dense" in g:
         d1, d2 = g["dense"][0], g["dense"][1]
-        assert np.array_equal(gsw.mult_dense(d1, d2), g["mult_dense_ref_format"])
+        # the reference's own ciphertext format as the left operand: the trait's mult / nand on the MFMA path ...
+        gsw.set_dense_fast(2)  # at any size (by default only from 1024 rows up, where it pays)
+        assert np.array_equal(gsw.mult_dense(d1, d2), g["mult_dense_ref_format"]) and gsw.last_dense_path() == 1
+        assert np.array_equal(gsw.nand_dense(d1, d2), g["nand_dense_ref_format"]) and gsw.last_dense_path() == 1
+        # ... and on the plain N^3 kernel
+        gsw.set_dense_fast(False)
+        assert np.array_equal(gsw.mult_dense(d1, d2), g["mult_dense_ref_format"]) and gsw.last_dense_path() == 0
         assert np.array_equal(gsw.nand_dense(d1, d2), g["nand_dense_ref_format"])
+        gsw.set_dense_fast(1)
         assert np.array_equal(gsw.add_dense(d1, d2), g["add_dense_ref_format"])
         assert np.array_equal(gsw.flatten_matrix(g["mult_dense_ref_format"]), g["flatten_quirk_of_product"])
         assert [gsw.decrypt_dense(sk, d) for d in g["dense"]] == g["decrypt_dense"].tolist()

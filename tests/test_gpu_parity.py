@@ -405,6 +405,84 @@ def test_dense_ops_arbitrary_entries(oracle, tfhe_amd, ring_name):
     assert gsw.bit_decomp_inv_matrix(ones)[0, 0] == oracle.bit_decomp_inv_matrix(ring_o, ones)[0, 0]
 
 
+@pytest.mark.parametrize("ring_name,n", [("fp", 10), ("z32", 7), ("z8", 9), ("fp", 40)])
+def test_dense_mult_of_reference_format_ciphertexts_runs_on_mfma(oracle, tfhe_amd, ring_name, n):
+    """FheScheme::mult / nand (gsw_impl.rs:104-123) on the reference's own N x N ciphertexts,
+    BitDecomp(R * A) + mu * I (gsw_impl.rs:27-42): the left operand is 0 / 1 off the diagonal, so the product
+    takes the MFMA contraction (path 1) and must equal the oracle's plain N^3 product; the right operand is
+    arbitrary (a previous product included).  Left operands that do not fit the form take the plain kernel."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    m = n * ring_o.ell
+    og = oracle.GSW(ring_o, n, m, seed=n, check_max=False)
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=n, check_max=False)
+    sk, pk = og.keygen()
+    big_n = ring_o.big_n(n)
+    rng = np.random.default_rng(n)
+    # default policy: the MFMA path from 1024 rows up; mode 2 takes it whenever the form fits
+    c1 = og.encrypt(pk, 1)
+    _assert_equal(gsw.mult_dense(c1, c1), og.mult(c1, c1), "default policy")
+    assert gsw.last_dense_path() == (1 if big_n >= 1024 else 0)
+    gsw.set_dense_fast(2)
+    for mu1, mu2 in ((1, 1), (0, 1), (5 % ring_o.q, 1), (ring_o.q - 1, 0)):
+        c1, c2 = og.encrypt(pk, mu1), og.encrypt(pk, mu2)
+        _assert_equal(gsw.mult_dense(c1, c2), og.mult(c1, c2), f"mult, messages {mu1}, {mu2}")
+        assert gsw.last_dense_path() == 1
+        _assert_equal(gsw.nand_dense(c1, c2), og.nand(c1, c2), f"nand, messages {mu1}, {mu2}")
+        assert gsw.last_dense_path() == 1
+    # the right operand may be anything: a product (entries up to q - 1), uniform noise
+    c1 = og.encrypt(pk, 1)
+    anything = rng.integers(0, ring_o.q, size=(big_n, big_n), dtype=np.uint64).astype(np.uint32)
+    _assert_equal(gsw.mult_dense(c1, anything), og.mult(c1, anything), "arbitrary right operand")
+    assert gsw.last_dense_path() == 1
+    if ring_name == "fp" and n == 10:  # decrypts like the reference's product (gsw_impl.rs:48-52)
+        osk = sk
+        prod = gsw.mult_dense(og.encrypt(pk, 1), og.encrypt(pk, 1))
+        assert og.decrypt(osk, prod) == 1
+    # one entry off the diagonal that is not 0 / 1: the plain kernel, same product
+    if ring_o.q > 2:
+        odd = c1.copy()
+        odd[3, big_n - 1] = 2
+        _assert_equal(gsw.mult_dense(odd, anything), og.mult(odd, anything), "misfit left operand")
+        assert gsw.last_dense_path() == 0
+    # extreme diagonals and an all-ones left operand
+    ones = np.ones((big_n, big_n), dtype=np.uint32)
+    np.fill_diagonal(ones, ring_o.q - 1)
+    _assert_equal(gsw.nand_dense(ones, anything), og.nand(ones, anything), "all ones, diagonal q - 1")
+    assert gsw.last_dense_path() == 1
+    gsw.set_dense_fast(0)
+    _assert_equal(gsw.mult_dense(c1, anything), og.mult(c1, anything), "plain kernel")
+    assert gsw.last_dense_path() == 0
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z32", "z30", "z8", "z1"])
+def test_gadget_decomposition_in_every_output_format(oracle, tfhe_amd, ring_name):
+    """G^-1 (helper.rs:7-21) as uint32 (the reference's matrix), as bytes, and as a packed bit string, against the
+    oracle's bit_decomp_matrix: ragged shapes (rows shorter and longer than one workgroup run, a padded leading
+    dimension, one column), extreme values."""
+    from tfhe_amd import _lib
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    gsw = tfhe_amd.GSW(ring_d, 2, 2 * ring_d.ell)
+    rng = np.random.default_rng(ring_o.ell)
+    for rows, cols, ld in ((7, 5, 5), (3, 1, 4), (5, 11, 16), (2, 300, 304), (1, 1500, 1500), (33, 140, 144)):
+        a = rng.integers(0, ring_o.q, size=(rows, cols), dtype=np.uint64).astype(np.uint32)
+        a[0, :] = ring_o.q - 1
+        a[rows - 1, cols - 1] = ring_o.q - 1
+        if rows > 1:
+            a[1, :] = 0
+        expect = oracle.bit_decomp_matrix(ring_o, a)  # rows x cols*ell, 0 / 1
+        _assert_equal(gsw.bit_decomp_as(a, _lib.DECOMP_U32, ld), expect, f"u32 {rows}x{cols}")
+        _assert_equal(gsw.bit_decomp_as(a, _lib.DECOMP_U8, ld), expect.astype(np.uint8), f"u8 {rows}x{cols}")
+        wide = cols * ring_o.ell
+        words = (wide + 31) // 32
+        padded = np.zeros((rows, words * 32), dtype=np.uint8)
+        padded[:, :wide] = expect
+        packed = np.packbits(padded, axis=1, bitorder="little").view(np.uint32).reshape(rows, words)
+        _assert_equal(gsw.bit_decomp_as(a, _lib.DECOMP_BITS, ld), packed, f"bits {rows}x{cols}")
+    with pytest.raises(tfhe_amd.GswError, match="format"):
+        gsw.bit_decomp_as(np.zeros((1, 1)), 7)
+
+
 def test_samplers_and_digest(oracle, tfhe_amd):
     ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
     gsw = tfhe_amd.GSW(ring_d, 2, 62, seed=9)

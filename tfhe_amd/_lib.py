@@ -29,6 +29,7 @@ class Gate(C.Structure):
 
 
 WIRE_CIPHERTEXT, WIRE_PUBLIC_KEY, WIRE_SECRET_KEY = 1, 2, 3
+DECOMP_U32, DECOMP_U8, DECOMP_BITS = 0, 1, 2
 GATE_MULT, GATE_NAND, GATE_ADD, GATE_MULT_CONST = 0, 1, 2, 3
 
 # every symbol include/gsw_hip.h declares: name -> (restype, argtypes)
@@ -59,12 +60,16 @@ SIGNATURES = {
     "gsw_upload_compact": (_i, [_vp, _vp, _vp]),
     "gsw_download_compact": (_i, [_vp, _vp, _vp]),
     "gsw_bit_decomp": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gsw_bit_decomp_row_elems": (_sz, [_vp, _i, _i]),
+    "gsw_bit_decomp_as": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
     "gsw_bit_decomp_inv": (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     "gsw_flatten": (_i, [_vp, _vp, _i, _i]),
     "gsw_add": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "gsw_mult_const": (_i, [_vp, _vp, _u32, _sz]),
     "gsw_mul_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
     "gsw_nand_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "gsw_ctx_set_dense_fast": (_i, [_vp, _i]),
+    "gsw_ctx_last_dense_path": (_i, [_vp]),
     "gsw_validate_compact": (_i, [_vp, _vp, _sz, _i, C.POINTER(_u64)]),
     "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),

@@ -95,6 +95,8 @@ struct gsw_ctx {
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
+    int dense_fast;        // MFMA path of gsw_mul_dense / gsw_nand_dense: 0 never, 1 from 1024 rows up, 2 whenever the form fits
+    int last_dense_path;   // 0 = plain dim^3 kernel, 1 = MFMA contraction (what the last dense product used)
     void *static_scratch;  // this GPU's copy of the library's static scratch array (gsw_mul_gadget_batch_static)
     bool in_static_call;   // inside gsw_mul_gadget_batch_static: nothing may allocate, not even timing events
     void *small;         // scratch of the helpers that return values to the host (row dots, tables, staging)
@@ -330,6 +332,7 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
         return fail(GSW_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    ctx->dense_fast = 1;
     ctx->overlap_chunk = 128;
     ctx->pass_rows = 8;
     ctx->pass_cols = 8;
@@ -602,7 +605,20 @@ int gsw_wire_read_compact(gsw_ctx *ctx, const void *h_in, size_t in_bytes, uint3
 int gsw_bit_decomp(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, uint32_t *d_out) {
     if (!ctx || !d_in || !d_out || rows < 0 || cols < 0 || ld_in < cols) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
-    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, d_in, rows, cols, ld_in, d_out, ctx->stream));
+    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, d_in, rows, cols, ld_in, d_out, gswk::kDecompU32, ctx->stream));
+    return GSW_OK;
+}
+
+size_t gsw_bit_decomp_row_elems(const gsw_ctx *ctx, int cols, int format) {
+    if (!ctx || cols < 0 || format < GSW_DECOMP_U32 || format > GSW_DECOMP_BITS) return 0;
+    return gswk::bit_decomp_pitch(cols, ctx->ring.ell, format);
+}
+
+int gsw_bit_decomp_as(gsw_ctx *ctx, const uint32_t *d_in, int rows, int cols, int ld_in, void *d_out, int format) {
+    if (!ctx || !d_in || !d_out || rows < 0 || cols < 0 || ld_in < cols) return fail(GSW_E_INVALID, "bad argument");
+    if (format < GSW_DECOMP_U32 || format > GSW_DECOMP_BITS) return fail(GSW_E_INVALID, "unknown decomposition format %d", format);
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, d_in, rows, cols, ld_in, d_out, format, ctx->stream));
     return GSW_OK;
 }
 
@@ -621,7 +637,7 @@ int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols) {
     if (int rc = ensure_small(ctx, (size_t)rows * cols * 4 + 16)) return rc;
     uint32_t *tmp = (uint32_t *)ctx->small;
     HIP_TRY(gswk::launch_bit_decomp_inv(ctx->ring, d_mat, rows, cols, tmp, cols, 1, ctx->stream));
-    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, tmp, rows, cols, cols, d_mat, ctx->stream));
+    HIP_TRY(gswk::launch_bit_decomp(ctx->ring, tmp, rows, cols, cols, d_mat, gswk::kDecompU32, ctx->stream));
     return GSW_OK;
 }
 
@@ -643,21 +659,104 @@ int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t co
     return GSW_OK;
 }
 
-int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim) {
+// mult / nand on the reference's own N x N matrices.  A left operand in the reference's ciphertext format
+// (entries 0 / 1 off the diagonal: BitDecomp(R * A) + mu * I, gsw_impl.rs:27-42) goes through the int8-MFMA
+// contraction with an N-column right operand plus a diagonal term; anything else -- arbitrary entries, a
+// dimension other than the context's N, a prepared operand beyond the workspace limit -- through the plain
+// dim^3 kernel.  Same results either way (both are the exact product over the ring).
+static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim, int nand) {
     if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
     if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
     if (int rc = use_device(ctx)) return rc;
-    HIP_TRY(gswk::launch_mul_dense(ctx->ring, d_c1, d_c2, d_out, dim, 0, ctx->stream));
+    ctx->last_dense_path = 0;
+    const bool packed_tail = ctx->gemm_variant == 9 && gswk::can_pack_tail(dim);
+    const size_t prep = gswk::prepared_bytes(dim, ctx->e4, packed_tail);
+    // below about a thousand rows the detection pass and its host synchronisation cost more than the plain
+    // kernel takes (N = 341: 0.06 ms against 0.02 ms); dense_fast == 2 takes the MFMA path at any size
+    const bool worth_it = ctx->dense_fast == 2 || (ctx->dense_fast == 1 && dim >= 1024);
+    const bool shape_fits = worth_it && ctx->gemm_variant == 9 && dim == ctx->big_n && dim > 0 && prep <= ctx->ws_limit;
+    if (shape_fits) {
+        // packed left operand (N x ld words), diagonal vector, misfit counter: from the context's scratch
+        const size_t packed_bytes = ((size_t)dim * ctx->ld * 4 + 255) & ~(size_t)255;
+        const size_t diag_bytes = ((size_t)dim * 4 + 255) & ~(size_t)255;
+        if (int rc = ensure_small(ctx, packed_bytes + diag_bytes + 256)) return rc;
+        uint32_t *packed = (uint32_t *)ctx->small;
+        uint32_t *diag = (uint32_t *)((uint8_t *)ctx->small + packed_bytes);
+        unsigned long long *d_misfits = (unsigned long long *)((uint8_t *)ctx->small + packed_bytes + diag_bytes);
+        HIP_TRY(gswk::launch_pack_flat_lhs(ctx->ring, d_c1, dim, ctx->width, ctx->ld, packed, diag, d_misfits, ctx->stream));
+        unsigned long long counts[2] = {0, 0};  // misfits, rows with a diagonal term
+        HIP_TRY(hipMemcpyAsync(counts, d_misfits, sizeof counts, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (counts[0] == 0) {
+            if (int rc = ensure_workspace(ctx, prep)) return rc;
+            gswk::PrepArgs pa{};
+            pa.src = d_c2;
+            pa.src_stride = 0;
+            pa.dst = (uint8_t *)ctx->ws;
+            pa.dst_stride = prep;
+            pa.rows_valid = dim;
+            pa.cols_valid = dim;
+            pa.ld_src = dim;
+            pa.elems = ctx->width;
+            pa.e4 = ctx->e4;
+            pa.batch = 1;
+            pa.packed_tail = packed_tail;
+            pa.layout16 = 1;
+            if (int rc = run_prepare(ctx, pa, ctx->stream)) return rc;
+            // The kernel places one batch entry per XCD at a time, so the single product is cut into slabs of
+            // `slab` rows that play the part of batch entries (same right operand, stride 0): a launch over the
+            // full slabs, then one over the remaining rows.
+            const int slab = dim >= 8 * 512 ? 512 : 256;
+            const int full = dim / slab;
+            for (int part = 0; part < 2; ++part) {
+                const int row0 = part == 0 ? 0 : full * slab;
+                const int rows = part == 0 ? slab : dim - full * slab;
+                const int entries = part == 0 ? full : 1;
+                if (entries == 0 || rows == 0) continue;
+                gswk::GemmArgs a{};
+                a.lhs = packed + (size_t)row0 * ctx->ld;
+                a.lhs_stride = (size_t)slab * ctx->ld;
+                a.rhs = (const uint8_t *)ctx->ws;
+                a.rhs_stride = 0;
+                a.out = d_out + (size_t)row0 * dim;
+                a.out_stride = (size_t)slab * dim;
+                a.rows = rows;
+                a.e4 = ctx->e4;
+                a.ld_lhs = ctx->ld;
+                a.out_cols = dim;
+                a.ld_out = dim;
+                a.batch = entries;
+                a.mode = gswk::kModeMul;
+                a.packed_tail = packed_tail;
+                if (int rc = run_gemm(ctx, a)) return rc;
+            }
+            // the diagonal term diag(d) * C2 and nand's I - P (gsw_impl.rs:114-123), when there is either
+            if (counts[1] != 0 || nand)
+                HIP_TRY(gswk::launch_dense_fixup(ctx->ring, d_out, d_c2, diag, dim, nand, ctx->stream));
+            ctx->last_dense_path = 1;
+            return GSW_OK;
+        }
+    }
+    HIP_TRY(gswk::launch_mul_dense(ctx->ring, d_c1, d_c2, d_out, dim, nand, ctx->stream));
     return GSW_OK;
 }
 
+int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim) {
+    return dense_product(ctx, d_c1, d_c2, d_out, dim, 0);
+}
+
 int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim) {
-    if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
-    if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
-    if (int rc = use_device(ctx)) return rc;
-    HIP_TRY(gswk::launch_mul_dense(ctx->ring, d_c1, d_c2, d_out, dim, 1, ctx->stream));
+    return dense_product(ctx, d_c1, d_c2, d_out, dim, 1);
+}
+
+int gsw_ctx_set_dense_fast(gsw_ctx *ctx, int enable) {
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (enable < 0 || enable > 2) return fail(GSW_E_INVALID, "dense path mode must be 0, 1 or 2");
+    ctx->dense_fast = enable;
     return GSW_OK;
 }
+
+int gsw_ctx_last_dense_path(const gsw_ctx *ctx) { return ctx ? ctx->last_dense_path : -1; }
 
 // ---- the hot path ----
 

@@ -88,8 +88,14 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
 // The prepared right operand must have been built for the variant's fragment order.
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
 
-hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, uint32_t *out,
-                             hipStream_t stream);
+// output formats of the gadget decomposition (GSW_DECOMP_* of the C header)
+constexpr int kDecompU32 = 0;   // one uint32 per bit: the reference's matrix of ring 0 / 1 values
+constexpr int kDecompU8 = 1;    // one byte per bit
+constexpr int kDecompBits = 2;  // the row's bits as a little-endian bit string, 32 per word
+// elements (uint32 / bytes / uint32 words) per output row, rows tight
+size_t bit_decomp_pitch(int cols, int ell, int format);
+hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, void *out,
+                             int format, hipStream_t stream);
 hipError_t launch_bit_decomp_inv(const RingDesc &ring, const uint32_t *in, int rows, int cols, uint32_t *out,
                                  int ld_out, int quirk, hipStream_t stream);
 hipError_t launch_add(const RingDesc &ring, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t count,
@@ -97,6 +103,14 @@ hipError_t launch_add(const RingDesc &ring, const uint32_t *a, const uint32_t *b
 hipError_t launch_mult_const(const RingDesc &ring, uint32_t *x, uint32_t k, size_t count, hipStream_t stream);
 hipError_t launch_mul_dense(const RingDesc &ring, const uint32_t *a, const uint32_t *b, uint32_t *out, int dim,
                             int nand, hipStream_t stream);
+// Dense product with a flattened left operand (see pack_flat_lhs_kernel): c1 dim x dim -> packed dim x ld words
+// of ell bits, diag[dim] (diagonal entries other than 0 / 1), misfits[0] = entries that do not fit the form,
+// misfits[1] = rows with a non-zero diag entry.
+hipError_t launch_pack_flat_lhs(const RingDesc &ring, const uint32_t *c1, int dim, int words, int ld, uint32_t *packed,
+                                uint32_t *diag, unsigned long long *misfits, hipStream_t stream);
+// out += diag(d) * c2, then out = I - out when nand
+hipError_t launch_dense_fixup(const RingDesc &ring, uint32_t *out, const uint32_t *c2, const uint32_t *diag, int dim,
+                              int nand, hipStream_t stream);
 // out[b * nrows + k] = <x_b[row0 + k, 0..cols), vec> mod q
 hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride, int ld, int cols, int row0,
                           int nrows, const uint32_t *vec, int batch, uint32_t *out, hipStream_t stream);

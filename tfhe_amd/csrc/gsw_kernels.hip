@@ -1088,15 +1088,144 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hip
 
 // ------------------------------------------------------------------ gadget helpers
 
-// bit_decomp_matrix (helper.rs:7-21): bit k of column j goes to column j*ell + k, little endian
-__global__ void bit_decomp_kernel(const uint32_t *in, int rows, int cols, int ld_in, uint32_t *out, int ell) {
-    const size_t wide = (size_t)cols * ell;
-    const size_t total = (size_t)rows * wide;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t i = idx / wide, jk = idx - i * wide;
-        const int j = (int)(jk / ell), k = (int)(jk - (size_t)j * ell);
-        out[idx] = (in[i * ld_in + j] >> k) & 1u;
+// bit_decomp_matrix (helper.rs:7-21): bit k of column j goes to column j*ell + k, little endian.
+//
+// G^-1 as a streaming kernel, in the format its consumer reads:
+//   kDecompU32  one uint32 (ring 0 / 1) per bit -- the reference's matrix (N x N: 254 MB at n = 256)
+//   kDecompU8   one byte per bit -- rows of an int8 MFMA operand
+//   kDecompBits the row's bits as one little-endian bit string, 32 per word -- the densest form
+// U32 / U8 (bit_slice_kernel): a workgroup takes 256 consecutive elements (row-major order) with one coalesced load,
+// every lane slices its element into ell outputs in LDS (lane t writes slots t*ell + k: an odd ell makes the
+// 64 lanes of a store hit distinct banks, an even one is skewed by the lane number), and the workgroup then
+// streams the staged segment to memory as 16-byte words, 1 KiB contiguous per wave instruction, with the few
+// outputs before the first and after the last 16-byte boundary stored singly.
+// Bits (bit_decomp_kernel): the input words of a run are staged instead and every lane gathers 128 output bits.
+// All index arithmetic is 32-bit; rows and segments are spread over the grid.
+constexpr int kSliceLanes = 256;
+
+template <typename OUT>
+__global__ __launch_bounds__(kSliceLanes) void bit_slice_kernel(const uint32_t *in, unsigned elems, unsigned cols,
+                                                                unsigned ld_in, OUT *out, int ell_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char slice_lds[];
+    OUT *stage = reinterpret_cast<OUT *>(slice_lds);
+    constexpr unsigned kVec = 16 / sizeof(OUT);  // outputs per 16-byte store
+    const unsigned ell = (unsigned)ell_;
+    const unsigned tid = threadIdx.x;
+    // Output rows are tight, so element e = row * cols + col of the matrix owns outputs [e * ell, (e + 1) * ell) of the
+    // flat output whatever its row: segments are runs of 256 consecutive elements and may cross rows.
+    const unsigned segs = (elems + kSliceLanes - 1) / kSliceLanes;
+    // an even ell would put every lane's slot k in the same bank: lane t starts its bits at k = t mod ell
+    const unsigned k_first = (ell & 1u) == 0 ? tid % ell : 0u;
+    for (unsigned seg = blockIdx.x; seg < segs; seg += gridDim.x) {
+        const unsigned e0 = seg * kSliceLanes;
+        const unsigned count = min((unsigned)kSliceLanes, elems - e0);  // elements of this segment
+        OUT *dst = out + (size_t)e0 * ell;
+        // The stage mirrors the destination from its last 16-byte boundary on: output i of the segment sits in
+        // slot mis + i, so 16-byte words of the stage are 16-byte words of memory.
+        const unsigned mis = (unsigned)((reinterpret_cast<uintptr_t>(dst) / sizeof(OUT)) % kVec);
+        __syncthreads();  // the previous segment has left the stage
+        if (tid < count) {
+            const unsigned e = e0 + tid, row = e / cols, col = e - row * cols;
+            const uint32_t x = in[(size_t)row * ld_in + col];
+            OUT *mine = stage + mis + tid * ell;
+            unsigned k = k_first;
+            for (unsigned i = 0; i < ell; ++i) {
+                mine[k] = (OUT)((x >> k) & 1u);
+                if (++k == ell) k = 0;
+            }
+        }
+        __syncthreads();
+        const unsigned end = mis + count * ell;                      // slots [mis, end) hold outputs
+        const unsigned v_first = mis ? 1u : 0u, v_end = end / kVec;  // whole 16-byte words [v_first, v_end)
+        OUT *base = dst - mis;                                        // 16-byte aligned
+        for (unsigned v = v_first + tid; v < v_end; v += kSliceLanes)
+            *reinterpret_cast<uint4 *>(base + v * kVec) = *reinterpret_cast<const uint4 *>(stage + v * kVec);
+        // the outputs before the first and after the last boundary, one by one
+        if (mis && mis + tid < min(kVec, end)) base[mis + tid] = stage[mis + tid];
+        const unsigned tail0 = max(v_end, v_first) * kVec;
+        if (tail0 + tid < end) base[tail0 + tid] = stage[tail0 + tid];
+    }
+}
+
+constexpr int kDecompLanes = 256;
+constexpr int kDecompStage = 4096;  // input words staged per run (+ 2 for the elements a run straddles)
+
+template <int FMT>
+__global__ __launch_bounds__(kDecompLanes) void bit_decomp_kernel(const uint32_t *in, int rows, int cols, int ld_in,
+                                                                  void *out_v, int ell_, unsigned out_pitch,
+                                                                  unsigned run_bits, unsigned runs_per_row) {
+    constexpr unsigned PER = FMT == kDecompU32 ? 4u : FMT == kDecompU8 ? 16u : 128u;  // output bits per lane
+    __shared__ uint32_t stage[kDecompStage + 2];
+    const unsigned ell = (unsigned)ell_;
+    const unsigned wide = (unsigned)cols * ell;  // bits per row
+    const unsigned total_runs = (unsigned)rows * runs_per_row;
+    for (unsigned run = blockIdx.x; run < total_runs; run += gridDim.x) {
+        const unsigned row = run / runs_per_row, o_base = (run - row * runs_per_row) * run_bits;
+        const unsigned j_base = o_base / ell;
+        const unsigned j_end = (min(o_base + run_bits, wide) + ell - 1u) / ell;  // one past the last element touched
+        const uint32_t *src = in + (size_t)row * ld_in;
+        __syncthreads();  // the previous run's readers are done with the stage
+        for (unsigned t = threadIdx.x; j_base + t < j_end; t += kDecompLanes) stage[t] = src[j_base + t];
+        __syncthreads();
+        const unsigned o0 = o_base + threadIdx.x * PER;
+        if (threadIdx.x * PER >= run_bits || o0 >= wide) continue;  // both barriers of this run are behind us
+        unsigned j = o0 / ell, k = o0 - j * ell;
+        if constexpr (FMT == kDecompBits) {
+            // 128 consecutive bits of the row's bit string: four words, each gathered from the elements it spans
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t acc = 0;
+                unsigned filled = 0;
+                while (filled < 32u && j < (unsigned)cols) {
+                    const uint32_t piece = stage[j - j_base] >> k;  // the ell - k bits of element j not yet used
+                    acc |= piece << filled;
+                    const unsigned take = min(ell - k, 32u - filled);
+                    filled += take;
+                    k += take;
+                    if (k == ell) { k = 0; ++j; }
+                }
+                // operands are canonical (< 2^ell), so `piece` never carries bits beyond the element
+                w[q] = filled < 32u ? acc & ((1u << filled) - 1u) : acc;
+            }
+            uint32_t *dst = (uint32_t *)out_v + (size_t)row * out_pitch + (o0 >> 5);
+            const unsigned words_left = out_pitch - (o0 >> 5);
+            if (words_left >= 4u && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+            else
+                for (unsigned q = 0; q < 4u && q < words_left; ++q) dst[q] = w[q];
+        } else {
+            uint32_t cur = stage[j - j_base] >> k;
+            uint32_t bits[PER];
+#pragma unroll
+            for (unsigned t = 0; t < PER; ++t) {
+                bits[t] = cur & 1u;
+                cur >>= 1;
+                if (++k == ell) {
+                    k = 0;
+                    ++j;
+                    cur = j < j_end ? stage[j - j_base] : 0u;
+                }
+            }
+            if constexpr (FMT == kDecompU32) {
+                uint32_t *dst = (uint32_t *)out_v + (size_t)row * out_pitch + o0;
+                if (o0 + 4u <= wide && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0)
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+                else
+                    for (unsigned t = 0; t < 4u && o0 + t < wide; ++t) dst[t] = bits[t];
+            } else {
+                uint8_t *dst = (uint8_t *)out_v + (size_t)row * out_pitch + o0;
+                if (o0 + 16u <= wide && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+                    uint32_t p4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        p4[q] = bits[4 * q] | bits[4 * q + 1] << 8 | bits[4 * q + 2] << 16 | bits[4 * q + 3] << 24;
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(p4[0], p4[1], p4[2], p4[3]);
+                } else {
+                    for (unsigned t = 0; t < 16u && o0 + t < wide; ++t) dst[t] = (uint8_t)bits[t];
+                }
+            }
+        }
     }
 }
 
@@ -1150,12 +1279,42 @@ static inline unsigned grid_for(size_t total, int block) {
     return (unsigned)g;
 }
 
-hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, uint32_t *out,
-                             hipStream_t stream) {
-    const size_t total = (size_t)rows * cols * ring.ell;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(bit_decomp_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, in, rows, cols, ld_in,
-                       out, ring.ell);
+size_t bit_decomp_pitch(int cols, int ell, int format) {
+    const size_t wide = (size_t)cols * ell;
+    return format == kDecompBits ? (wide + 31) / 32 : wide;  // in output elements (words / bytes / words)
+}
+
+hipError_t launch_bit_decomp(const RingDesc &ring, const uint32_t *in, int rows, int cols, int ld_in, void *out,
+                             int format, hipStream_t stream) {
+    const size_t wide = (size_t)cols * ring.ell;
+    if (rows <= 0 || wide == 0) return hipSuccess;
+    if (wide > 0x7FFFFFFFu || format < kDecompU32 || format > kDecompBits) return hipErrorInvalidValue;
+    const unsigned per = format == kDecompU32 ? 4u : format == kDecompU8 ? 16u : 128u;
+    // a run is what one workgroup iteration covers: every lane's share, but no more input than the stage holds
+    unsigned run = kDecompLanes * per;
+    if ((size_t)kDecompStage * ring.ell < run) run = (unsigned)(kDecompStage * ring.ell) / per * per;
+    const unsigned runs_per_row = (unsigned)((wide + run - 1) / run);
+    const size_t total_runs = (size_t)rows * runs_per_row;
+    if (total_runs > 0xFFFFFFFFu) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(total_runs < 256u * 32u ? total_runs : 256u * 32u);
+    const unsigned pitch = (unsigned)bit_decomp_pitch(cols, ring.ell, format);
+    if (format != kDecompBits) {
+        const size_t elems = (size_t)rows * cols;
+        if (elems > 0xFFFFFFFFu - kSliceLanes) return hipErrorInvalidValue;
+        const size_t segs = (elems + kSliceLanes - 1) / kSliceLanes;
+        const unsigned sgrid = (unsigned)(segs < 256u * 16u ? segs : 256u * 16u);
+        const size_t elem = format == kDecompU32 ? 4 : 1;
+        const size_t lds = (((size_t)kSliceLanes * ring.ell + 16) * elem + 15) & ~(size_t)15;  // + one word of skew
+        if (format == kDecompU32)
+            hipLaunchKernelGGL(bit_slice_kernel<uint32_t>, dim3(sgrid), dim3(kSliceLanes), lds, stream, in,
+                               (unsigned)elems, (unsigned)cols, (unsigned)ld_in, (uint32_t *)out, ring.ell);
+        else
+            hipLaunchKernelGGL(bit_slice_kernel<uint8_t>, dim3(sgrid), dim3(kSliceLanes), lds, stream, in,
+                               (unsigned)elems, (unsigned)cols, (unsigned)ld_in, (uint8_t *)out, ring.ell);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(bit_decomp_kernel<kDecompBits>, dim3(grid), dim3(kDecompLanes), 0, stream, in, rows, cols, ld_in,
+                       out, ring.ell, pitch, run, runs_per_row);
     return hipGetLastError();
 }
 
@@ -1227,6 +1386,88 @@ __global__ __launch_bounds__(256) void mul_dense_kernel(const uint32_t *a, const
         }
         out[(size_t)row * dim + col] = val;
     }
+}
+
+// ---- dense product with a flattened left operand: the reference's own ciphertext format on the MFMA path.
+//
+// A default-feature ciphertext is BitDecomp(R * A) + mu * I (gsw_impl.rs:27-42): entries in {0, 1} except for
+// the diagonal, which carries the message on top.  For such a left operand C1 = B + diag(d), B binary,
+//     C1 * C2 = B * C2 + diag(d) * C2,
+// and B * C2 is the binary x byte-limb contraction with an N-column right operand.  pack_flat_lhs_kernel
+// packs B into ell-bit words (the layout of a compact ciphertext), extracts d, and counts the entries that do
+// not fit the form (anything but 0 / 1 off the diagonal); dense_fixup_kernel adds the diagonal term and applies
+// nand's I - P (gsw_impl.rs:114-123).
+
+__global__ __launch_bounds__(256) void pack_flat_lhs_kernel(const uint32_t *c1, int dim, int ell, int words, int ld,
+                                                             uint32_t *packed, uint32_t *diag,
+                                                             unsigned long long *misfits) {
+    const size_t total = (size_t)dim * ld;
+    unsigned bad = 0, scaled = 0;  // misfits; rows whose diagonal entry is neither 0 nor 1
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int i = (int)(idx / (size_t)ld), j = (int)(idx - (size_t)i * ld);
+        uint32_t w = 0;
+        if (j < words) {
+            const uint32_t *src = c1 + (size_t)i * dim + (size_t)j * ell;
+            for (int k = 0; k < ell; ++k) {
+                const uint32_t v = src[k];
+                if (j * ell + k == i) {
+                    // the diagonal entry: 0 / 1 stay in B, anything else goes to d
+                    if (v <= 1u) { w |= v << k; diag[i] = 0u; }
+                    else { diag[i] = v; ++scaled; }
+                } else {
+                    bad += v > 1u;
+                    w |= (v & 1u) << k;
+                }
+            }
+        }
+        packed[idx] = w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad += (unsigned)__shfl_xor((int)bad, off, 64);
+        scaled += (unsigned)__shfl_xor((int)scaled, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicAdd(&misfits[0], (unsigned long long)bad);
+        if (scaled) atomicAdd(&misfits[1], (unsigned long long)scaled);
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(256) void dense_fixup_kernel(uint32_t *out, const uint32_t *c2, const uint32_t *diag,
+                                                           int dim, int nand, uint32_t mask) {
+    const size_t total = (size_t)dim * dim;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int i = (int)(idx / (size_t)dim), j = (int)(idx - (size_t)i * dim);
+        uint32_t v = out[idx];
+        const uint32_t d = diag[i];
+        if (d) v = ring_add<RING>(v, ring_mul<RING>(d, c2[idx], mask), mask);
+        if (nand) {
+            v = ring_sub<RING>(0u, v, mask);
+            if (i == j) v = ring_add<RING>(v, ring_from_u64<RING>(1ull, mask), mask);
+        }
+        out[idx] = v;
+    }
+}
+
+hipError_t launch_pack_flat_lhs(const RingDesc &ring, const uint32_t *c1, int dim, int words, int ld, uint32_t *packed,
+                                uint32_t *diag, unsigned long long *misfits, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(misfits, 0, 2 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess || dim <= 0) return e;
+    hipLaunchKernelGGL(pack_flat_lhs_kernel, dim3(grid_for((size_t)dim * ld, 256)), dim3(256), 0, stream, c1, dim,
+                       ring.ell, words, ld, packed, diag, misfits);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_fixup(const RingDesc &ring, uint32_t *out, const uint32_t *c2, const uint32_t *diag, int dim,
+                              int nand, hipStream_t stream) {
+    if (dim <= 0) return hipSuccess;
+    dim3 grid(grid_for((size_t)dim * dim, 256)), block(256);
+    if (ring.kind == kRingFp)
+        hipLaunchKernelGGL(dense_fixup_kernel<kRingFp>, grid, block, 0, stream, out, c2, diag, dim, nand, ring.mask);
+    else
+        hipLaunchKernelGGL(dense_fixup_kernel<kRingZpow2>, grid, block, 0, stream, out, c2, diag, dim, nand, ring.mask);
+    return hipGetLastError();
 }
 
 hipError_t launch_mul_dense(const RingDesc &ring, const uint32_t *a, const uint32_t *b, uint32_t *out, int dim,

@@ -504,8 +504,19 @@ class GSW:
         check(fn(eng.handle, d_a.ptr, d_b.ptr, d_o.ptr, dim))
         return d_o.download(np.uint32, a.size).reshape(dim, dim)
 
+    def set_dense_fast(self, mode) -> None:
+        """MFMA path of the dense products (see mult_dense): 0 / False never, 1 / True from 1024 rows up (the
+        default), 2 whenever the left operand has the form."""
+        check(_lib.lib().gsw_ctx_set_dense_fast(self.engine.handle, int(mode)))
+
+    def last_dense_path(self) -> int:
+        """Which kernel the last dense product used: 0 = the plain N^3 kernel, 1 = the MFMA contraction."""
+        return int(_lib.lib().gsw_ctx_last_dense_path(self.engine.handle))
+
     def mult_dense(self, c1, c2) -> np.ndarray:
-        """src/gsw/gsw_impl.rs:104-111 (default features): the plain N x N x N product."""
+        """src/gsw/gsw_impl.rs:104-111 (default features): the N x N x N product on the reference's own
+        matrices.  A left operand in the reference's ciphertext format (0 / 1 off the diagonal) runs on the
+        MFMA contraction, anything else on the plain kernel; the results are the same."""
         return self._dense_binary(_lib.lib().gsw_mul_dense, c1, c2)
 
     def nand_dense(self, c1, c2) -> np.ndarray:
@@ -555,6 +566,23 @@ class GSW:
         d_in.upload(a)
         check(_lib.lib().gsw_bit_decomp(eng.handle, d_in.ptr, rows, cols, cols, d_out.ptr))
         return d_out.download(np.uint32, a.size * eng.ell).reshape(rows, cols * eng.ell)
+
+    def bit_decomp_as(self, a, fmt: int, ld_in: Optional[int] = None) -> np.ndarray:
+        """bit_decomp_matrix in another storage format: _lib.DECOMP_U8 gives one byte per bit, _lib.DECOMP_BITS the
+        row's bits as a little-endian bit string packed 32 per uint32 (rows of ceil(cols * ell / 32) words)."""
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        rows, cols = a.shape
+        eng, L = self.engine, _lib.lib()
+        ld_in = cols if ld_in is None else ld_in
+        padded = np.zeros((rows, ld_in), dtype=np.uint32)
+        padded[:, :cols] = a
+        per_row = L.gsw_bit_decomp_row_elems(eng.handle, cols, fmt)
+        dtype = np.uint8 if fmt == _lib.DECOMP_U8 else np.uint32
+        d_in = eng.alloc_u32(padded.size)
+        d_out = eng.alloc(max(rows * per_row * np.dtype(dtype).itemsize, 16))
+        d_in.upload(padded)
+        check(L.gsw_bit_decomp_as(eng.handle, d_in.ptr, rows, cols, ld_in, d_out.ptr, fmt))
+        return d_out.download(dtype, rows * per_row).reshape(rows, per_row)
 
     def bit_decomp_inv_matrix(self, a, quirk: bool = True) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.uint32)
