@@ -79,6 +79,9 @@ int gsw_ctx_enable_timing(gsw_ctx *ctx, int enable);
 /* which: 0 = contraction kernel, 1 = right-operand preparation.  Waits for the stream. */
 int gsw_ctx_kernel_time(gsw_ctx *ctx, int which, double *total_ms, long *launches);
 int gsw_ctx_reset_timing(gsw_ctx *ctx);
+/* work counters since the context was created: right operands put into prepared form (the public key of
+ * gsw_prepare_pk included) and batch entries handed to the contraction kernel */
+int gsw_ctx_counters(const gsw_ctx *ctx, uint64_t *prepared_operands, uint64_t *contracted_products);
 
 /* ---- device memory helpers (plain hipMalloc / hipMemcpy on the context's GPU) ---- */
 int gsw_malloc(gsw_ctx *ctx, size_t bytes, void **d_ptr);

@@ -125,6 +125,37 @@ def test_one_level_longer_than_a_pipeline_chunk(oracle, tfhe_amd):
     assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
 
 
+def test_shared_right_operands_are_prepared_once(oracle, tfhe_amd):
+    """Gates of one run that multiply by the same slot share one prepared operand: the levelised XOR circuit's
+    second level has two gates per bit with the same right operand; a fan-out of one operand over a run longer
+    than a pipeline chunk prepares it once per chunk.  Results against the oracle as ever."""
+    ring_o, ring_d = oracle.zpow2(30), tfhe_amd.Zpow2(30)
+    n, bits = 2, 6
+    gsw = tfhe_amd.GSW(ring_d, n, n * 30, seed=12)
+    og = oracle.GSW(ring_o, n, n * 30)
+    rng = np.random.default_rng(12)
+    start = rng.integers(0, ring_o.q, size=(6 * bits, ring_o.big_n(n), n + 1), dtype=np.uint64).astype(np.uint32)
+    gates = _xor_gates(bits, levelised=True)  # levels of 6, 12 and 6 products; level 2 has 6 distinct right operands
+    pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+    prepared0, products0 = gsw.engine.counters()
+    gsw.eval_circuit(pool, gates)
+    prepared1, products1 = gsw.engine.counters()
+    assert products1 - products0 == 4 * bits and prepared1 - prepared0 == 3 * bits
+    assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
+    # 300 products by one right operand and by two alternating ones, through the chunked pipeline
+    inputs, count = 8, 300
+    start = np.zeros((inputs + count, ring_o.big_n(n), n + 1), dtype=np.uint32)
+    start[:inputs] = rng.integers(0, ring_o.q, size=(inputs,) + start.shape[1:], dtype=np.uint64).astype(np.uint32)
+    for rhs_of in (lambda i: 3, lambda i: 3 + (i & 1)):
+        gates = [("nand", i % inputs, rhs_of(i), inputs + i) for i in range(count)]
+        pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+        prepared0, _ = gsw.engine.counters()
+        gsw.eval_circuit(pool, gates)
+        prepared1, _ = gsw.engine.counters()
+        assert prepared1 - prepared0 <= 2 * 6  # at most two distinct operands in each of at most six chunks
+        assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
+
+
 def test_bad_gates_are_rejected(tfhe_amd):
     gsw = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62, seed=1)
     pool = tfhe_amd.Ciphertext(gsw.engine, 4)

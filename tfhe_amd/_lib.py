@@ -52,6 +52,7 @@ SIGNATURES = {
     "gsw_ctx_enable_timing": (_i, [_vp, _i]),
     "gsw_ctx_kernel_time": (_i, [_vp, _i, C.POINTER(_dbl), C.POINTER(C.c_long)]),
     "gsw_ctx_reset_timing": (_i, [_vp]),
+    "gsw_ctx_counters": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "gsw_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "gsw_free": (_i, [_vp, _vp]),
     "gsw_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),

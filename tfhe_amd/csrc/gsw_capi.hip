@@ -95,6 +95,7 @@ struct gsw_ctx {
     void *ws;
     size_t ws_bytes;
     size_t ws_limit;
+    uint64_t n_prepared, n_products;  // right operands prepared / products contracted since creation
     int dense_fast;        // MFMA path of gsw_mul_dense / gsw_nand_dense: 0 never, 1 from 1024 rows up, 2 whenever the form fits
     int last_dense_path;   // 0 = plain dim^3 kernel, 1 = MFMA contraction (what the last dense product used)
     void *static_scratch;  // this GPU's copy of the library's static scratch array (gsw_mul_gadget_batch_static)
@@ -219,6 +220,7 @@ int check_no_alias(const gsw_ctx *ctx, const uint32_t *operand, size_t stride, s
 
 int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &args) {
     gswk::GemmArgs a = args;
+    ctx->n_products += (uint64_t)(a.batch > 0 ? a.batch : 0);
     a.pass_rows = ctx->pass_rows;
     a.pass_cols = ctx->pass_cols;
     ScopedTimer timer(ctx, 0, ctx->stream);
@@ -227,6 +229,7 @@ int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &args) {
 }
 
 int run_prepare(gsw_ctx *ctx, const gswk::PrepArgs &a, hipStream_t stream) {
+    ctx->n_prepared += (uint64_t)(a.batch > 0 ? a.batch : 0);
     ScopedTimer timer(ctx, 1, stream);
     HIP_TRY(gswk::launch_prepare(ctx->ring, a, stream));
     return GSW_OK;
@@ -398,6 +401,13 @@ int gsw_ctx_set_workspace_limit(gsw_ctx *ctx, size_t bytes) {
 int gsw_ctx_enable_timing(gsw_ctx *ctx, int enable) {
     if (!ctx) return fail(GSW_E_INVALID, "null context");
     ctx->timing = enable != 0;
+    return GSW_OK;
+}
+
+int gsw_ctx_counters(const gsw_ctx *ctx, uint64_t *prepared_operands, uint64_t *contracted_products) {
+    if (!ctx || !prepared_operands || !contracted_products) return fail(GSW_E_INVALID, "bad argument");
+    *prepared_operands = ctx->n_prepared;
+    *contracted_products = ctx->n_products;
     return GSW_OK;
 }
 
@@ -807,7 +817,7 @@ int gsw_prepare_rhs(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void
 static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const void *d_prepared,
                         size_t stride_prepared_bytes, uint32_t *d_out, size_t stride_out, int batch, unsigned flags,
                         uint64_t *d_digests, const uint32_t *d_lhs_slots = nullptr,
-                        const uint32_t *d_out_slots = nullptr) {
+                        const uint32_t *d_out_slots = nullptr, const uint32_t *d_rhs_slots = nullptr) {
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_prepared || !aligned16(d_prepared) || (stride_prepared_bytes & 15u))
@@ -832,6 +842,7 @@ static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, con
     a.digests = (unsigned long long *)d_digests;
     a.lhs_slot = d_lhs_slots;
     a.out_slot = d_out_slots;
+    a.rhs_slot = d_rhs_slots;
     return run_gemm(ctx, a);
 }
 
@@ -845,10 +856,46 @@ int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1,
                         nullptr);
 }
 
-// Slot lists (device arrays of `batch` entries, all three or none): entry b then uses
-// d_c1c + lhs[b] * stride1, d_c2c + rhs[b] * stride2 and d_out + out[b] * stride_out.
+// How a batch is cut into chunks of prepared right operands: pipelined over the two workspace halves (the
+// preparation of chunk k+1 beside the contraction of chunk k) or one after another on one stream.
+struct ChunkPlan {
+    bool pipelined = false;
+    size_t capacity = 0;                         // right operands one workspace half (or the workspace) holds
+    std::vector<std::pair<size_t, int>> chunks;  // (first entry, entries)
+};
+
+static ChunkPlan plan_chunks(const gsw_ctx *ctx, int batch) {
+    ChunkPlan plan;
+    const size_t prep = gsw_ctx_prepared_bytes(ctx);
+    size_t pipe_chunk = (size_t)ctx->overlap_chunk;
+    // shorter batches (one level of a circuit) still get four chunks to overlap, down to 32 products
+    if (pipe_chunk && (size_t)batch < 4 * pipe_chunk) pipe_chunk = (size_t)batch / 4 > 32 ? (size_t)batch / 4 : 32;
+    if (pipe_chunk > ctx->ws_limit / (2 * prep)) pipe_chunk = ctx->ws_limit / (2 * prep);
+    if (pipe_chunk >= 1 && (size_t)batch > pipe_chunk) {
+        plan.pipelined = true;
+        plan.capacity = pipe_chunk;
+        // the first chunk's preparation is the only one nothing hides: keep it to a quarter chunk
+        size_t step = pipe_chunk >= 64 ? pipe_chunk / 4 : pipe_chunk;
+        for (size_t b0 = 0; b0 < (size_t)batch; b0 += step, step = pipe_chunk)
+            plan.chunks.emplace_back(b0, (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step));
+        return plan;
+    }
+    size_t chunk = ctx->ws_limit / prep;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)batch) chunk = (size_t)batch;
+    plan.capacity = chunk;
+    for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk)
+        plan.chunks.emplace_back(b0, (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk));
+    return plan;
+}
+
+// Slot lists of a gate-list run (device arrays): entry b uses d_c1c + lhs[b] * stride1 and d_out + out[b] * stride_out.
+// Right operands: per chunk of the plan, `rhs_distinct` lists each distinct slot once -- that many operands are
+// prepared -- and rhs_index[b] says which of them entry b multiplies by.
 struct SlotLists {
-    const uint32_t *lhs = nullptr, *rhs = nullptr, *out = nullptr;
+    const uint32_t *lhs = nullptr, *out = nullptr, *rhs_index = nullptr, *rhs_distinct = nullptr;
+    const ChunkPlan *plan = nullptr;
+    const std::vector<int> *distinct_counts = nullptr;  // per chunk of the plan
     explicit operator bool() const { return lhs != nullptr; }
 };
 
@@ -872,63 +919,55 @@ static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const 
         if (int rc = gsw_prepare_rhs(ctx, d_c2c, 0, ctx->ws, 1)) return rc;
         return mul_prepared(ctx, d_c1c, stride1, ctx->ws, 0, d_out, stride_out, batch, flags, d_digests);
     }
-    size_t pipe_chunk = (size_t)ctx->overlap_chunk;
-    // shorter batches (one level of a circuit) still get four chunks to overlap, down to 32 products
-    if (pipe_chunk && (size_t)batch < 4 * pipe_chunk) pipe_chunk = (size_t)batch / 4 > 32 ? (size_t)batch / 4 : 32;
-    if (pipe_chunk > ctx->ws_limit / (2 * prep)) pipe_chunk = ctx->ws_limit / (2 * prep);
-    if (pipe_chunk >= 1 && (size_t)batch > pipe_chunk) {
-        // Two-stage pipeline over chunks: the (HBM-bound) preparation of chunk k+1 runs on the auxiliary
-        // stream beside the (MFMA-bound) contraction of chunk k; two workspace halves, events for the
-        // hand-offs in both directions, no host synchronisation.
-        if (int rc = ensure_workspace(ctx, 2 * pipe_chunk * prep)) return rc;
-        // The pipeline body reports failures through its return value; whatever it had enqueued on the
-        // auxiliary stream by then is joined into ctx->stream below, so that no preparation keeps writing
-        // a workspace half unordered with the caller's next call.
-        auto pipeline = [&]() -> int {
+    ChunkPlan own_plan;
+    if (!slots) own_plan = plan_chunks(ctx, batch);
+    const ChunkPlan &plan = slots ? *slots.plan : own_plan;
+    if (int rc = ensure_workspace(ctx, (plan.pipelined ? 2 : 1) * plan.capacity * prep)) return rc;
+    // The body reports failures through its return value; whatever it had enqueued on the auxiliary stream by
+    // then is joined into ctx->stream below, so that no preparation keeps writing a workspace half unordered
+    // with the caller's next call.
+    auto body = [&]() -> int {
+        hipStream_t prep_stream = plan.pipelined ? ctx->aux_stream : ctx->stream;
+        if (plan.pipelined) {
+            // Two-stage pipeline over chunks: the (HBM-bound) preparation of chunk k+1 runs on the auxiliary
+            // stream beside the (MFMA-bound) contraction of chunk k; two workspace halves, events for the
+            // hand-offs in both directions, no host synchronisation.
             HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
             HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
-            // the first chunk's preparation is the only one nothing hides: keep it to a quarter chunk
-            size_t k = 0, step = pipe_chunk >= 64 ? pipe_chunk / 4 : pipe_chunk;
-            for (size_t b0 = 0; b0 < (size_t)batch; b0 += step, step = pipe_chunk, ++k) {
-                const int cur = (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step);
-                const int half = (int)(k & 1);
-                uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * pipe_chunk * prep;
-                if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
-                const size_t o = slots ? 0 : b0;  // with slot lists the bases stay put and the lists advance
-                if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ws, cur, ctx->aux_stream,
-                                            slots ? slots.rhs + b0 : nullptr))
+        }
+        size_t distinct_seen = 0;
+        for (size_t k = 0; k < plan.chunks.size(); ++k) {
+            const size_t b0 = plan.chunks[k].first;
+            const int cur = plan.chunks[k].second;
+            const int half = plan.pipelined ? (int)(k & 1) : 0;
+            uint8_t *ws = (uint8_t *)ctx->ws + (size_t)half * plan.capacity * prep;
+            if (plan.pipelined && k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
+            if (slots) {
+                // with slot lists the bases stay put and the lists advance; each distinct right operand once
+                const int distinct = (*slots.distinct_counts)[k];
+                if (int rc = prepare_rhs_on(ctx, d_c2c, stride2, ws, distinct, prep_stream, slots.rhs_distinct + distinct_seen))
                     return rc;
+                distinct_seen += (size_t)distinct;
+            } else if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, ws, cur, prep_stream)) {
+                return rc;
+            }
+            if (plan.pipelined) {
                 HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
                 HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
-                if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ws, prep, d_out + o * stride_out,
-                                          stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr,
-                                          slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
-                    return rc;
-                HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
             }
-            return GSW_OK;
-        };
-        const int rc = pipeline();
-        if (rc != GSW_OK) join_aux(ctx);
-        return rc;
-    }
-    // one stream, workspace-sized chunks
-    size_t chunk = ctx->ws_limit / prep;
-    if (chunk < 1) chunk = 1;
-    if (chunk > (size_t)batch) chunk = (size_t)batch;
-    if (int rc = ensure_workspace(ctx, chunk * prep)) return rc;
-    for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
-        const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
-        const size_t o = slots ? 0 : b0;
-        if (int rc = prepare_rhs_on(ctx, d_c2c + o * stride2, stride2, ctx->ws, cur, ctx->stream,
-                                    slots ? slots.rhs + b0 : nullptr))
-            return rc;
-        if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ctx->ws, prep, d_out + o * stride_out,
-                                  stride_out, cur, flags, d_digests ? d_digests + b0 : nullptr,
-                                  slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr))
-            return rc;
-    }
-    return GSW_OK;
+            const size_t o = slots ? 0 : b0;
+            if (int rc = mul_prepared(ctx, d_c1c + o * stride1, stride1, ws, prep, d_out + o * stride_out, stride_out,
+                                      cur, flags, d_digests ? d_digests + b0 : nullptr,
+                                      slots ? slots.lhs + b0 : nullptr, slots ? slots.out + b0 : nullptr,
+                                      slots ? slots.rhs_index + b0 : nullptr))
+                return rc;
+            if (plan.pipelined) HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
+        }
+        return GSW_OK;
+    };
+    const int rc = body();
+    if (rc != GSW_OK && plan.pipelined) join_aux(ctx);
+    return rc;
 }
 
 int gsw_mul_gadget_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
@@ -1017,6 +1056,9 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         size_t first, count;  // product gates [first, first+count) of the packed slot lists; count 0 = elementwise gate
         size_t gate;          // index into h_gates of an elementwise gate
         unsigned flags;
+        ChunkPlan plan;               // how the run's products are cut into chunks of prepared right operands
+        std::vector<int> distinct;    // per chunk: distinct right-operand slots (each is prepared once)
+        size_t distinct_first = 0;    // where the run's distinct lists start in the staged array
     };
     std::vector<Run> runs;
     std::vector<uint32_t> lhs, rhs, out;
@@ -1026,7 +1068,7 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
     for (size_t i = 0; i < n_gates; ++i) {
         const gsw_gate &g = h_gates[i];
         if (g.op == GSW_GATE_ADD || g.op == GSW_GATE_MULT_CONST) {
-            runs.push_back({0, 0, i, 0});
+            runs.push_back({0, 0, i, 0, {}, {}, 0});
             open = false;
             continue;
         }
@@ -1034,7 +1076,7 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         const bool hazard = open && (written_in[g.a] == run_id || written_in[g.b] == run_id ||
                                      written_in[g.out] == run_id || read_in[g.out] == run_id);
         if (!open || hazard || runs.back().flags != flags) {
-            runs.push_back({lhs.size(), 0, 0, flags});
+            runs.push_back({lhs.size(), 0, 0, flags, {}, {}, 0});
             ++run_id;
             open = true;
         }
@@ -1046,16 +1088,45 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         ++runs.back().count;
     }
 
+    // Right operands: within a chunk every distinct slot is prepared once, whatever the number of gates that
+    // multiply by it; rhs_index[b] is entry b's position in its chunk's list of distinct slots.
     const size_t products = lhs.size();
+    std::vector<uint32_t> rhs_index(products), rhs_distinct;
+    rhs_distinct.reserve(products);
+    {
+        std::vector<uint32_t> position(n_slots, 0), stamp(n_slots, 0);
+        uint32_t chunk_id = 0;
+        for (Run &r : runs) {
+            if (r.count == 0) continue;
+            r.plan = plan_chunks(ctx, (int)r.count);
+            r.distinct_first = rhs_distinct.size();
+            for (const auto &c : r.plan.chunks) {
+                ++chunk_id;
+                uint32_t distinct = 0;
+                for (size_t b = r.first + c.first; b < r.first + c.first + (size_t)c.second; ++b) {
+                    const uint32_t slot = rhs[b];
+                    if (stamp[slot] != chunk_id) {
+                        stamp[slot] = chunk_id;
+                        position[slot] = distinct++;
+                        rhs_distinct.push_back(slot);
+                    }
+                    rhs_index[b] = position[slot];
+                }
+                r.distinct.push_back((int)distinct);
+            }
+        }
+    }
+
     if (products) {
-        if (3 * products > ctx->slots_cap) {
+        const size_t staged = 3 * products + rhs_distinct.size();
+        if (staged > ctx->slots_cap) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             if (ctx->d_slots) HIP_TRY(hipFree(ctx->d_slots));
             if (ctx->h_slots) HIP_TRY(hipHostFree(ctx->h_slots));
             ctx->d_slots = nullptr;
             ctx->h_slots = nullptr;
             ctx->slots_cap = 0;
-            const size_t cap = 3 * products < 4096 ? 4096 : 3 * products;
+            const size_t cap = 4 * products < 4096 ? 4096 : 4 * products;
             HIP_TRY(hipMalloc((void **)&ctx->d_slots, cap * sizeof(uint32_t)));
             HIP_TRY(hipHostMalloc((void **)&ctx->h_slots, cap * sizeof(uint32_t), hipHostMallocDefault));
             ctx->slots_cap = cap;
@@ -1063,9 +1134,10 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
             HIP_TRY(hipEventSynchronize(ctx->ev_slots));  // the previous upload has left the staging buffer
         }
         memcpy(ctx->h_slots, lhs.data(), products * sizeof(uint32_t));
-        memcpy(ctx->h_slots + products, rhs.data(), products * sizeof(uint32_t));
+        memcpy(ctx->h_slots + products, rhs_index.data(), products * sizeof(uint32_t));
         memcpy(ctx->h_slots + 2 * products, out.data(), products * sizeof(uint32_t));
-        HIP_TRY(hipMemcpyAsync(ctx->d_slots, ctx->h_slots, 3 * products * sizeof(uint32_t), hipMemcpyHostToDevice,
+        memcpy(ctx->h_slots + 3 * products, rhs_distinct.data(), rhs_distinct.size() * sizeof(uint32_t));
+        HIP_TRY(hipMemcpyAsync(ctx->d_slots, ctx->h_slots, staged * sizeof(uint32_t), hipMemcpyHostToDevice,
                                ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev_slots, ctx->stream));
     }
@@ -1085,8 +1157,11 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         }
         SlotLists sl;
         sl.lhs = ctx->d_slots + r.first;
-        sl.rhs = ctx->d_slots + products + r.first;
+        sl.rhs_index = ctx->d_slots + products + r.first;
         sl.out = ctx->d_slots + 2 * products + r.first;
+        sl.rhs_distinct = ctx->d_slots + 3 * products + r.distinct_first;
+        sl.plan = &r.plan;
+        sl.distinct_counts = &r.distinct;
         if (int rc = mul_batch(ctx, d_pool, slot_stride, d_pool, slot_stride, d_pool, slot_stride, (int)r.count,
                                r.flags, nullptr, sl))
             return rc;

@@ -47,10 +47,12 @@ struct GemmArgs {
     int packed_tail;              // the last column tile is a packed one (see prepared_bytes)
     int pass_rows, pass_cols;     // placement passes of the blocked workgroup order (row tiles x column tiles)
     unsigned long long *digests;  // optional: digests[b] += digest of the stored tile (zeroed by the caller)
-    // optional slot lists (device, `batch` entries): entry b reads lhs + lhs_slot[b] * lhs_stride and writes
+    // optional slot lists (device, `batch` entries): entry b reads lhs + lhs_slot[b] * lhs_stride and
+    // rhs + rhs_slot[b] * rhs_stride (several entries may share one prepared right operand) and writes
     // out + out_slot[b] * out_stride; null means slot b
     const uint32_t *lhs_slot;
     const uint32_t *out_slot;
+    const uint32_t *rhs_slot;
 };
 
 inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }

@@ -511,7 +511,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
     const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     const int stages = p.e4 / kStageElems;
     const bool wave_active = mt * kRows + wave * 64 < p.rows;
 
@@ -689,7 +689,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
     const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     const int stages = p.e4 / kStageElems;
     const bool wave_active = mt * kRows + wave * 64 < p.rows;
 
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
     if (!map_workgroup(p.batch, nt_count, mt_count, b, nt, mt)) return;
 
     const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + (size_t)b * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     int row_load = mt * kTileRows + tid;
     if (row_load > p.rows - 1) row_load = p.rows - 1;  // clamped rows are computed but never stored
     const uint32_t *a_src = lhs + (size_t)row_load * p.ld_lhs;

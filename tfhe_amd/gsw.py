@@ -131,6 +131,12 @@ class Engine:
     def reset_timing(self):
         check(_lib.lib().gsw_ctx_reset_timing(self.handle))
 
+    def counters(self):
+        """(right operands prepared, products contracted) since the context was created."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(_lib.lib().gsw_ctx_counters(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def kernel_time(self, which: int):
         ms, count = C.c_double(0), C.c_long(0)
         check(_lib.lib().gsw_ctx_kernel_time(self.handle, which, C.byref(ms), C.byref(count)))
