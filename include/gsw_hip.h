@@ -189,6 +189,18 @@ typedef struct gsw_gate {
 int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
                      size_t n_gates);
 
+/* Same, with a cache of prepared right operands beside the pool, so that a slot is put into prepared form once
+ * and not once per gate that multiplies by it: d_prepared_pool holds n_slots entries of gsw_ctx_prepared_bytes()
+ * each (entry s belongs to slot s); h_valid[s] != 0 says entry s currently is the prepared form of slot s.  A
+ * product whose right operand is valid runs without any preparation; one whose operand is stale prepares it into
+ * its entry first and sets the flag; every gate clears the flag of the slot it writes.  The flags are the
+ * caller's array (in/out): set them for entries filled otherwise (gsw_encrypt_batch_prepared, gsw_prepare_rhs) and
+ * clear them for slots changed behind the library's back.  A run of independent products is one contraction
+ * launch straight out of the cache.  A list the checks reject leaves flags and pool untouched; a failure after
+ * launches have begun clears every flag. */
+int gsw_eval_circuit_cached(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, void *d_prepared_pool,
+                            uint8_t *h_valid, const gsw_gate *h_gates, size_t n_gates);
+
 /* ---- encrypt (gsw_impl.rs:27-42): compact form R * pk + message * G, the same contraction
  *      with the N x m random bit matrix as the binary operand ---- */
 /* pk_matrix (pk.rs:28-38), m x (n + 1) row-major tight on the HOST -> prepared device form */
@@ -200,6 +212,13 @@ int gsw_pack_rbits(gsw_ctx *ctx, const uint8_t *h_bits /* N x m */, uint32_t *d_
 int gsw_random_rbits(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_rbits, int batch);
 int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
                       const uint32_t *d_messages /* batch values */, uint32_t *d_out, size_t stride_out, int batch);
+
+/* gsw_encrypt_batch that also leaves every fresh ciphertext in prepared form (entry b at d_prepared_out +
+ * b * gsw_ctx_prepared_bytes()), the form in which a product reads its right operand: acc <- mult(acc, fresh)
+ * chains then never prepare anything (gsw_mul_gadget_prepared, gsw_eval_circuit_cached) */
+int gsw_encrypt_batch_prepared(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
+                               const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, void *d_prepared_out,
+                               int batch);
 
 /* ---- decrypt (gsw_impl.rs:48-52) and mp_decrypt (gsw_impl.rs:67-84) on compact ciphertexts.
  *      h_s is sk.s = (1, -t) (sk.rs:20-24) on the host; <C[i,:], v> = <Cc[i,:], s>. ---- */

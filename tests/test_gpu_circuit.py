@@ -156,6 +156,84 @@ def test_shared_right_operands_are_prepared_once(oracle, tfhe_amd):
         assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
 
 
+def test_cached_gate_lists_match_the_oracle_and_prepare_each_slot_once(oracle, tfhe_amd):
+    """gsw_eval_circuit_cached: the random hazard-laden gate list gives the oracle's pool, every slot is prepared at
+    most once between two writes to it, and a rejected list leaves the flags alone."""
+    ring_o, ring_d = oracle.fp(), tfhe_amd.Fp()
+    n, slots = 3, 12
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=3)
+    og = oracle.GSW(ring_o, n, n * 31)
+    rng = np.random.default_rng(19)
+    start = rng.integers(0, ring_o.q, size=(slots, ring_o.big_n(n), n + 1), dtype=np.uint64).astype(np.uint32)
+    gates = []
+    for _ in range(80):
+        kind = rng.choice(["mult", "nand", "nand", "mult", "add", "mult_const"])
+        a, out = int(rng.integers(slots)), int(rng.integers(slots))
+        if kind == "mult_const":
+            gates.append((kind, a, int(rng.integers(ring_o.q)), out))
+            continue
+        b = int(rng.integers(slots))
+        if kind != "add":
+            while out in (a, b):
+                out = int(rng.integers(slots))
+        gates.append((kind, a, b, out))
+    pool = tfhe_amd.Ciphertext.from_compact(gsw.engine, start)
+    cache = tfhe_amd.PreparedCache(gsw.engine, slots)
+    gsw.eval_circuit(pool, gates[:50], cache=cache)
+    gsw.eval_circuit(pool, gates[50:], cache=cache)  # the flags carry over from call to call
+    assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, start, gates))
+    # the flags tell the truth: every entry marked valid is the prepared form of its slot -- a fan-out over all
+    # slots as right operands, half of them through entries the earlier lists left valid, must agree
+    fan = [("mult", 0, s, slots + s) for s in range(slots)]
+    big = np.concatenate([pool.to_compact(), np.zeros_like(start)])
+    pool2 = tfhe_amd.Ciphertext.from_compact(gsw.engine, big)
+    cache2 = tfhe_amd.PreparedCache(gsw.engine, 2 * slots)
+    cache2.valid[:slots] = cache.valid
+    from tfhe_amd import _lib
+    _lib.check(_lib.lib().gsw_memcpy_d2h(gsw.engine.handle, (tmp := np.empty(slots * gsw.engine.prepared_bytes, np.uint8)).ctypes.data,
+                                         cache.buf.ptr, tmp.size))
+    _lib.check(_lib.lib().gsw_memcpy_h2d(gsw.engine.handle, cache2.buf.ptr, tmp.ctypes.data, tmp.size))
+    assert 0 < int(cache.valid.sum()) <= slots
+    prepared0, _ = gsw.engine.counters()
+    gsw.eval_circuit(pool2, fan, cache=cache2)
+    prepared1, _ = gsw.engine.counters()
+    assert prepared1 - prepared0 == slots - int(cache.valid.sum())  # only the stale ones
+    assert np.array_equal(pool2.to_compact(), _apply_on_oracle(oracle, og, big, fan))
+    assert cache2.valid[:slots].all() and not cache2.valid[slots:].any()
+    gsw.eval_circuit(pool2, fan, cache=cache2)  # everything valid now: no preparation at all
+    assert gsw.engine.counters()[0] == prepared1
+    with pytest.raises(tfhe_amd.GswError, match="own operand"):
+        gsw.eval_circuit(pool2, fan + [("mult", 1, 2, 1)], cache=cache2)
+    assert cache2.valid[:slots].all() and not cache2.valid[slots:].any()  # a rejected list changes nothing
+
+
+def test_chain_over_fresh_encryptions_in_prepared_form_prepares_nothing(oracle, tfhe_amd):
+    ring_o, ring_d = oracle.fp(), tfhe_amd.Fp()
+    n, chains, depth = 10, 5, 4
+    gsw = tfhe_amd.GSW(ring_d, n, 310, seed=44)
+    og = oracle.GSW(ring_o, n, 310)
+    sk, pk = gsw.keygen()
+    pool = tfhe_amd.Ciphertext(gsw.engine, chains * (2 + depth))
+    cache = tfhe_amd.PreparedCache(gsw.engine, pool.batch)
+    msgs = [[1, 1, 0, 1, 1]] + [[1, 1, 1, 1, 1]] * (depth - 2) + [[1, 0, 1, 1, 1]]
+    gsw.encrypt_batch(pk, [1] * chains, out=pool, slot=0)
+    for lvl in range(depth):
+        gsw.encrypt_batch(pk, msgs[lvl], out=pool, slot=chains * (2 + lvl), cache=cache)
+    before = pool.to_compact()
+    gates = []
+    for lvl in range(depth):
+        src, dst = (0, chains) if lvl % 2 == 0 else (chains, 0)
+        gates += [("mult", src + c, chains * (2 + lvl) + c, dst + c) for c in range(chains)]
+    prepared0, products0 = gsw.engine.counters()
+    gsw.eval_circuit(pool, gates, cache=cache)
+    prepared1, products1 = gsw.engine.counters()
+    assert prepared1 == prepared0 and products1 - products0 == chains * depth
+    assert np.array_equal(pool.to_compact(), _apply_on_oracle(oracle, og, before, gates))
+    final = 0 if depth % 2 == 0 else chains
+    want = [int(all(msgs[lvl][c] for lvl in range(depth))) for c in range(chains)]
+    assert gsw.decrypt_batch(sk, pool, slot=final, count=chains).tolist() == want
+
+
 def test_bad_gates_are_rejected(tfhe_amd):
     gsw = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62, seed=1)
     pool = tfhe_amd.Ciphertext(gsw.engine, 4)

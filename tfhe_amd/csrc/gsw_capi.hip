@@ -337,10 +337,14 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     ctx->stream = ctx->own_stream;
     ctx->dense_fast = 1;
     ctx->overlap_chunk = 128;
-    ctx->pass_rows = 8;
-    ctx->pass_cols = 8;
-    if (const char *v = getenv("GSW_PASS_ROWS")) ctx->pass_rows = atoi(v) > 0 ? atoi(v) : 8;
-    if (const char *v = getenv("GSW_PASS_COLS")) ctx->pass_cols = atoi(v) > 0 ? atoi(v) : 8;
+    // placement passes (row tiles x column tiles an XCD works on together): 8 x 8, and 16 x 4 once a product has
+    // a dozen column tiles (n = 512: a right-operand panel is 2.1 MB there, and taller passes re-read it half
+    // as often; +1..2 % on the kernel, level at n = 256)
+    const bool wide = gswk::col_tiles(ctx->width) >= 12;
+    ctx->pass_rows = wide ? 16 : 8;
+    ctx->pass_cols = wide ? 4 : 8;
+    if (const char *v = getenv("GSW_PASS_ROWS")) ctx->pass_rows = atoi(v) > 0 ? atoi(v) : ctx->pass_rows;
+    if (const char *v = getenv("GSW_PASS_COLS")) ctx->pass_cols = atoi(v) > 0 ? atoi(v) : ctx->pass_cols;
     if (const char *v = getenv("GSW_OVERLAP_CHUNK")) ctx->overlap_chunk = atoi(v) > 0 ? atoi(v) : 0;
     *out = ctx;
     return GSW_OK;
@@ -771,7 +775,7 @@ int gsw_ctx_last_dense_path(const gsw_ctx *ctx) { return ctx ? ctx->last_dense_p
 // ---- the hot path ----
 
 static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c, void *d_prepared, int batch,
-                          hipStream_t stream, const uint32_t *d_slots = nullptr) {
+                          hipStream_t stream, const uint32_t *d_slots = nullptr, const uint32_t *d_dst_slots = nullptr) {
     if (!ctx || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (batch == 0) return GSW_OK;
     if (!d_c2c || !d_prepared || !aligned16(d_prepared)) return fail(GSW_E_INVALID, "null or unaligned operand");
@@ -790,6 +794,7 @@ static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
     a.src_slot = d_slots;
+    a.dst_slot = d_dst_slots;
     return run_prepare(ctx, a, stream);
 }
 
@@ -1026,11 +1031,14 @@ int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
 
 // ---- gate lists over a pool of resident ciphertexts ----
 
-int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
-                     size_t n_gates) try {
+// d_cache / h_valid: optional cache of prepared right operands beside the pool (gsw_eval_circuit_cached)
+static int eval_circuit_impl(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
+                             size_t n_gates, void *d_cache, uint8_t *h_valid) {
     if (!ctx) return fail(GSW_E_INVALID, "null context");
     if (n_gates == 0) return GSW_OK;
     if (!d_pool || !h_gates) return fail(GSW_E_INVALID, "null operand");
+    if ((d_cache != nullptr) != (h_valid != nullptr) || (d_cache && !aligned16(d_cache)))
+        return fail(GSW_E_INVALID, "the prepared-operand cache needs a 16-byte aligned device array and its host flags");
     const size_t elems = gsw_ctx_compact_elems(ctx);
     if (!aligned16(d_pool) || (slot_stride & 3u) || slot_stride < elems)
         return fail(GSW_E_INVALID, "pool must be 16-byte aligned with a slot stride >= %zu and a multiple of 4", elems);
@@ -1088,12 +1096,12 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
         ++runs.back().count;
     }
 
-    // Right operands: within a chunk every distinct slot is prepared once, whatever the number of gates that
-    // multiply by it; rhs_index[b] is entry b's position in its chunk's list of distinct slots.
     const size_t products = lhs.size();
     std::vector<uint32_t> rhs_index(products), rhs_distinct;
     rhs_distinct.reserve(products);
-    {
+    if (!d_cache) {
+        // Right operands: within a chunk every distinct slot is prepared once, whatever the number of gates
+        // that multiply by it; rhs_index[b] is entry b's position in its chunk's list of distinct slots.
         std::vector<uint32_t> position(n_slots, 0), stamp(n_slots, 0);
         uint32_t chunk_id = 0;
         for (Run &r : runs) {
@@ -1114,6 +1122,28 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
                 }
                 r.distinct.push_back((int)distinct);
             }
+        }
+    } else {
+        // With a cache every slot's prepared form lives in its own cache entry: a run prepares the right
+        // operands whose entry is stale (each once), multiplies straight out of the cache, and the slots it
+        // writes go stale.  The flags are walked in list order here, on the host, before anything is launched.
+        for (Run &r : runs) {
+            if (r.count == 0) {
+                h_valid[h_gates[r.gate].out] = 0;  // add / mult_const overwrite their output slot
+                continue;
+            }
+            r.distinct_first = rhs_distinct.size();
+            uint32_t missing = 0;
+            for (size_t b = r.first; b < r.first + r.count; ++b) {
+                rhs_index[b] = rhs[b];  // the cache entry is the slot number
+                if (!h_valid[rhs[b]]) {
+                    h_valid[rhs[b]] = 1;
+                    rhs_distinct.push_back(rhs[b]);
+                    ++missing;
+                }
+            }
+            r.distinct.push_back((int)missing);
+            for (size_t b = r.first; b < r.first + r.count; ++b) h_valid[out[b]] = 0;
         }
     }
 
@@ -1155,6 +1185,19 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
             }
             continue;
         }
+        if (d_cache) {
+            // stale right operands into their cache entries, then the whole run as one contraction out of the cache
+            const uint32_t *missing = ctx->d_slots + 3 * products + r.distinct_first;
+            const size_t prep = gsw_ctx_prepared_bytes(ctx);
+            if (r.distinct[0] > 0)
+                if (int rc = prepare_rhs_on(ctx, d_pool, slot_stride, d_cache, r.distinct[0], ctx->stream, missing, missing))
+                    return rc;
+            if (int rc = mul_prepared(ctx, d_pool, slot_stride, d_cache, prep, d_pool, slot_stride, (int)r.count, r.flags,
+                                      nullptr, ctx->d_slots + r.first, ctx->d_slots + 2 * products + r.first,
+                                      ctx->d_slots + products + r.first))
+                return rc;
+            continue;
+        }
         SlotLists sl;
         sl.lhs = ctx->d_slots + r.first;
         sl.rhs_index = ctx->d_slots + products + r.first;
@@ -1167,6 +1210,27 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
             return rc;
     }
     return GSW_OK;
+}
+
+int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
+                     size_t n_gates) try {
+    return eval_circuit_impl(ctx, d_pool, slot_stride, n_slots, h_gates, n_gates, nullptr, nullptr);
+}
+GSW_CATCH
+
+int gsw_eval_circuit_cached(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, void *d_prepared_pool,
+                            uint8_t *h_valid, const gsw_gate *h_gates, size_t n_gates) try {
+    if (n_gates && (!d_prepared_pool || !h_valid)) return fail(GSW_E_INVALID, "null prepared-operand cache");
+    if (n_gates == 0 || !ctx) return eval_circuit_impl(ctx, d_pool, slot_stride, n_slots, h_gates, n_gates, nullptr, nullptr);
+    // The flags are walked ahead of the launches, on a copy: a list rejected by the checks leaves the caller's
+    // flags (and the pool) as they were; a failure once launches have begun leaves them all cleared, because
+    // the copy no longer describes the cache; success writes the copy back.
+    std::vector<uint8_t> valid(h_valid, h_valid + n_slots);
+    const uint64_t launched_before = ctx->n_prepared + ctx->n_products;
+    const int rc = eval_circuit_impl(ctx, d_pool, slot_stride, n_slots, h_gates, n_gates, d_prepared_pool, valid.data());
+    if (rc == GSW_OK) memcpy(h_valid, valid.data(), n_slots);
+    else if (ctx->n_prepared + ctx->n_products != launched_before) memset(h_valid, 0, n_slots);
+    return rc;
 }
 GSW_CATCH
 
@@ -1252,6 +1316,15 @@ int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d
     a.mode = gswk::kModeEncrypt;
     a.packed_tail = ctx->packed_tail;
     return run_gemm(ctx, a);
+}
+
+int gsw_encrypt_batch_prepared(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
+                               const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, void *d_prepared_out,
+                               int batch) {
+    if (batch > 0 && (!d_prepared_out || !aligned16(d_prepared_out))) return fail(GSW_E_INVALID, "null or unaligned prepared output");
+    if (int rc = gsw_encrypt_batch(ctx, d_pk_prepared, d_rbits, stride_rbits, d_messages, d_out, stride_out, batch)) return rc;
+    // the fresh ciphertexts straight into the form a product reads its right operand in
+    return prepare_rhs_on(ctx, d_out, stride_out, d_prepared_out, batch, ctx->stream);
 }
 
 // ---- decrypt ----

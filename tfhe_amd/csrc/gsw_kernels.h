@@ -80,6 +80,7 @@ struct PrepArgs {
     int packed_tail;
     int layout16;  // fragment order of the 16x16x64 kernels (variants 4, 5) instead of the 32x32x32 ones
     const uint32_t *src_slot;  // optional slot list (device, `batch` entries) into src; null means slot b
+    const uint32_t *dst_slot;  // optional slot list into dst (a cache of prepared operands); null means slot b
 };
 
 hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t stream);

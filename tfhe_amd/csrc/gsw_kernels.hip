@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
             }
         }
     }
-    uint8_t *dst = a.dst + (size_t)b * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
+    uint8_t *dst = a.dst + slot_of(a.dst_slot, b) * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
     if (packed) {
         const int l = cidx >> 3;
         tile[(32 * h + cidx) * 4 + i] = l == 0 ? limb[0] : l == 1 ? limb[1] : l == 2 ? limb[2] : limb[3];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
         }
     }
     __syncthreads();
-    uint8_t *dst = a.dst + (size_t)b * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
+    uint8_t *dst = a.dst + slot_of(a.dst_slot, b) * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
     if (packed) {
         if (tid < 128)
             reinterpret_cast<uint4 *>(dst + (size_t)blockIdx.x * (2 * kFragBytes))[tid] =
@@ -889,6 +889,17 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int b, nt, mt;
     if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
+#if defined(GSW_EXP_DEPHASE) || defined(GSW_EXP_PRIO)
+    // experiments on the two workgroups that share a CU (ids 256 apart: 8 XCDs x 32 CUs are filled first)
+    const bool second = (blockIdx.x >> 8) & 1;
+#endif
+#ifdef GSW_EXP_DEPHASE
+    if (second)
+        for (int i = 0; i < GSW_EXP_DEPHASE; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+#endif
+#ifdef GSW_EXP_PRIO
+    if (second) __builtin_amdgcn_s_setprio(GSW_EXP_PRIO);
+#endif
     if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, 4, true>(p, ell, mask, b, nt, mt, smem);
     else gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
 }

@@ -211,6 +211,19 @@ class Ciphertext:
         return dense.download(np.uint32, e.big_n * e.big_n).reshape(e.big_n, e.big_n)
 
 
+class PreparedCache:
+    """Prepared right operands beside a pool of ciphertexts (gsw_eval_circuit_cached): entry s is the prepared form
+    of pool slot s when valid[s] is set."""
+
+    def __init__(self, engine: Engine, slots: int):
+        self.engine, self.slots = engine, int(slots)
+        self.buf = engine.alloc(engine.prepared_bytes * self.slots)
+        self.valid = np.zeros(self.slots, dtype=np.uint8)
+
+    def entry_ptr(self, slot: int) -> int:
+        return self.buf.ptr + self.engine.prepared_bytes * slot
+
+
 @dataclass
 class SecretKey:
     """GswSk (src/gsw/sk.rs:13-17): t, s = (1, -t), v = PowersOf2(s)."""
@@ -354,12 +367,13 @@ class GSW:
         return sk, self.make_pk(rand_b.reshape(self.m, self.n), err, t)
 
     def encrypt_batch(self, pk: PublicKey, messages: Sequence[int], rbits=None, out: Optional[Ciphertext] = None,
-                      slot: int = 0) -> Ciphertext:
+                      slot: int = 0, cache: Optional[PreparedCache] = None) -> Ciphertext:
         """Batched src/gsw/gsw_impl.rs:27-42 in compact form: R * pk_matrix + message * G.
 
         rbits: optional (batch, N, m) 0/1 bytes standing for rnd_dmatrix(N, m, 0, 1); when absent the
         seeded device generator draws them.  out / slot: write the ciphertexts into entries slot, slot + 1, ..
-        of an existing batch (a pool for eval_circuit) instead of a new one.
+        of an existing batch (a pool for eval_circuit) instead of a new one.  cache: also leave the prepared
+        form of every fresh ciphertext in the cache entries of those slots (gsw_encrypt_batch_prepared).
         """
         eng, L = self.engine, _lib.lib()
         if pk.prepared is None:
@@ -381,8 +395,16 @@ class GSW:
             if slot < 0 or slot + batch > out.batch:
                 raise ValueError(f"entries {slot}..{slot + batch - 1} do not fit a batch of {out.batch}")
             ct, dst = out, out.entry_ptr(slot)
-        check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr,
-                                  ct.ptr if dst is None else dst, ct.stride, batch))
+        target = ct.ptr if dst is None else dst
+        if cache is None:
+            check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, target, ct.stride,
+                                      batch))
+        else:
+            if slot + batch > cache.slots:
+                raise ValueError("the prepared-operand cache is shorter than the pool range written")
+            check(L.gsw_encrypt_batch_prepared(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, target,
+                                               ct.stride, cache.entry_ptr(slot), batch))
+            cache.valid[slot:slot + batch] = 1
         eng.sync()
         return ct
 
@@ -484,17 +506,24 @@ class GSW:
 
     GATE_OPS = {"mult": 0, "nand": 1, "add": 2, "mult_const": 3}
 
-    def eval_circuit(self, pool: Ciphertext, gates) -> None:
+    def eval_circuit(self, pool: Ciphertext, gates, cache: Optional[PreparedCache] = None) -> None:
         """Apply (op, a, b, out) gates over the slots of `pool` (a batch of resident ciphertexts), in list
         order: op is "mult" / "nand" / "add" / "mult_const" (src/gsw/gsw_impl.rs:87-123; for mult_const
-        b is the constant).  Independent consecutive products run as one batched contraction."""
+        b is the constant).  Independent consecutive products run as one batched contraction.  With a
+        PreparedCache every slot is put into prepared form at most once until it is overwritten."""
         gates = list(gates)
         arr = (_lib.Gate * len(gates))()
         for i, (op, ga, gb, out) in enumerate(gates):
             if op not in self.GATE_OPS:
                 raise ValueError(f"unknown gate op {op!r}")
             arr[i] = _lib.Gate(self.GATE_OPS[op], int(ga), int(gb), int(out))
-        check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, arr, len(gates)))
+        if cache is None:
+            check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, arr, len(gates)))
+            return
+        if cache.slots != pool.batch:
+            raise ValueError("the prepared-operand cache must have one entry per pool slot")
+        check(_lib.lib().gsw_eval_circuit_cached(self.engine.handle, pool.ptr, pool.stride, pool.batch, cache.buf.ptr,
+                                                 cache.valid.ctypes.data, arr, len(gates)))
 
     # ---- the reference's dense operations on arbitrary matrices ----
     def _dense_binary(self, fn, a, b) -> np.ndarray:

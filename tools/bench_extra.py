@@ -63,6 +63,23 @@ def main():
                             "products_per_s": chains * depth / sec, "launch_sequences": depth,
                             "decrypts_correctly": True}
 
+    # the same chains with the fresh factors already in prepared form (encrypt_batch(..., cache=)): no preparation
+    # launch at any level, one contraction launch per level
+    cache = tfhe_amd.PreparedCache(eng, pool.batch)
+    gsw.encrypt_batch(pk, ones, out=pool, slot=0)
+    for lvl in range(depth):
+        msgs = [0 if (lvl == zero_level and c == zero_chain) else 1 for c in range(chains)]
+        gsw.encrypt_batch(pk, msgs, out=pool, slot=chains * (2 + lvl), cache=cache)
+    prepared0, _ = eng.counters()
+    gsw.eval_circuit(pool, gates, cache=cache)
+    eng.sync()
+    assert gsw.decrypt_batch(sk, pool, slot=final, count=chains).tolist() == want
+    sec = timed(eng, lambda: gsw.eval_circuit(pool, gates, cache=cache), repeat=2)
+    out["chains_depth8_prepared_factors"] = {"chains": chains, "products": chains * depth, "seconds_per_job": sec,
+                                             "products_per_s": chains * depth / sec,
+                                             "operands_prepared_during_the_chains": eng.counters()[0] - prepared0,
+                                             "decrypts_correctly": True}
+
     sec = timed(eng, lambda: gsw.decrypt_batch(sk, pool, slot=final, count=chains))
     out["decrypt"] = {"batch": chains, "decryptions_per_s": chains / sec}
     print(json.dumps(out))
