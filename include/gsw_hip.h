@@ -250,6 +250,16 @@ int gsw_fill_uniform(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint64_t min,
 /* NaiveSampler (error_sampling.rs:73-84) and DiscrGaussianSampler (error_sampling.rs:32-71) */
 int gsw_sample_naive(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_out, size_t count);
 int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sigma, uint32_t *d_out, size_t count);
+/* keygen (gsw_impl.rs:17-25) with nothing but the secret crossing to the host: t <- U[0, max]^n, e from the sampler
+ * (m values), B <- U[0, max]^(m x n) on generator streams first_stream, +1, +2 (the order of gsw_impl.rs:18-21);
+ * b = B t + e, pk_matrix = [b | B] (pk.rs:23-39) and its prepared form are made on the device.  h_t_out receives t
+ * (GswSk::new, sk.rs:20-28, is host logic on n + 1 values); d_pk_matrix_out (m rows x gsw_ctx_ld() uint32, may be
+ * NULL) the matrix; d_pk_prepared (gsw_ctx_pk_prepared_bytes()) what gsw_encrypt_batch reads.  Fails with
+ * GSW_E_INVALID when max > P unless `unchecked`, as the reference asserts (error_sampling.rs:21). */
+#define GSW_SAMPLER_NAIVE 0    /* NaiveSampler, error_sampling.rs:73-84 */
+#define GSW_SAMPLER_GAUSSIAN 1 /* DiscrGaussianSampler, error_sampling.rs:32-71 */
+int gsw_keygen_device(gsw_ctx *ctx, uint64_t seed, uint64_t first_stream, int sampler, double sigma, int unchecked,
+                      uint32_t *h_t_out, uint32_t *d_pk_matrix_out, void *d_pk_prepared);
 /* 64-bit position-weighted digest of each batch entry (count uint32 each) */
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch,
                      uint64_t *d_digests);

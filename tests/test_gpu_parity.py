@@ -251,6 +251,38 @@ def test_keygen_encrypt_decrypt(oracle, tfhe_amd, ring_name, n, sampler):
     assert gsw.decrypt_dense(sk, ct.to_dense(1)) == 0
 
 
+@pytest.mark.parametrize("ring_name,n,sampler", [("fp", 10, "gaussian"), ("fp", 6, "naive"), ("z32", 5, "gaussian"),
+                                                  ("z30", 10, 3.2), ("fp", 40, "gaussian")])
+def test_device_keygen_equals_the_oracle_and_the_host_assembled_key(oracle, tfhe_amd, ring_name, n, sampler):
+    """keygen on the device (samples, b = B t + e, pk_matrix, prepared form: nothing but t crosses to the host)
+    gives, draw for draw, the oracle's keygen (gsw_impl.rs:17-25) of the same seed -- uniform draws bit for bit;
+    the Gaussian errors come from the same table sampler on the same stream -- and the key that make_pk assembles
+    through the host from the same draws; the prepared form encrypts like the oracle's pk."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    m = n * ring_d.ell + 3
+    checked = ring_name != "z32"
+    gsw = tfhe_amd.GSW(ring_d, n, m, sampler=sampler, seed=99, check_max=checked)
+    sk, pk = gsw.keygen()
+    again = tfhe_amd.GSW(ring_d, n, m, sampler=sampler, seed=99, check_max=checked)
+    sk2, pk2 = again.keygen_host_assembled()
+    _assert_equal(sk.t, sk2.t, "t")
+    _assert_equal(pk.pk_matrix, pk2.pk_matrix, "pk_matrix, device against host assembly")
+    og = oracle.GSW(ring_o, n, m, sampler=sampler, seed=99, check_max=checked)
+    osk, opk = og.keygen()
+    _assert_equal(sk.t, osk.t, "t against the oracle")
+    _assert_equal(sk.s, osk.s, "s")
+    _assert_equal(sk.v, osk.v, "v")
+    _assert_equal(pk.pk_matrix, opk.pk_matrix, "pk_matrix against the oracle")
+    rbits = np.stack([og.random_bits() for _ in range(2)])
+    ct = gsw.encrypt_batch(pk, [1, 0], rbits=rbits)
+    for b, mu in enumerate((1, 0)):
+        _assert_equal(ct.to_compact()[b], og.encrypt_compact(opk, mu, rbits[b]), f"encryption under the device key [{b}]")
+    assert gsw.decrypt_batch(sk, ct).tolist() == [1, 0]
+    # without the download the key still encrypts
+    sk3, pk3 = tfhe_amd.GSW(ring_d, n, m, sampler=sampler, seed=99, check_max=checked).keygen(download=False)
+    assert pk3.pk_matrix is None and np.array_equal(sk3.t, sk.t)
+
+
 def test_encrypt_matches_oracle(oracle, tfhe_amd):
     """Batched encryption product R * pk + mu * G against the oracle, R given on the host."""
     for ring_name, n in (("fp", 10), ("z32", 7), ("fp", 8)):

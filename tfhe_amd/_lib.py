@@ -29,6 +29,7 @@ class Gate(C.Structure):
 
 
 WIRE_CIPHERTEXT, WIRE_PUBLIC_KEY, WIRE_SECRET_KEY = 1, 2, 3
+SAMPLER_NAIVE, SAMPLER_GAUSSIAN = 0, 1
 DECOMP_U32, DECOMP_U8, DECOMP_BITS = 0, 1, 2
 GATE_MULT, GATE_NAND, GATE_ADD, GATE_MULT_CONST = 0, 1, 2, 3
 
@@ -93,6 +94,7 @@ SIGNATURES = {
     "gsw_fill_uniform": (_i, [_vp, _u64, _u64, _u64, _u64, _i, _vp, _sz]),
     "gsw_sample_naive": (_i, [_vp, _u64, _u64, _vp, _sz]),
     "gsw_sample_gaussian": (_i, [_vp, _u64, _u64, _dbl, _vp, _sz]),
+    "gsw_keygen_device": (_i, [_vp, _u64, _u64, _i, _dbl, _i, _vp, _vp, _vp]),
     "gsw_wire_bytes": (_sz, [_vp, _i, _i]),
     "gsw_wire_write_host": (_i, [_vp, _i, _vp, _vp, _sz]),
     "gsw_wire_read_host": (_i, [_vp, _i, _vp, _sz, _vp]),

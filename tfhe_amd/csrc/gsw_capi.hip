@@ -1477,6 +1477,65 @@ int gsw_sample_gaussian(gsw_ctx *ctx, uint64_t seed, uint64_t stream, double sig
 }
 GSW_CATCH
 
+// keygen (gsw_impl.rs:17-25) without the host in the data path: the samples, b = B t + e, pk_matrix = [b | B] and its
+// prepared form are all made on the device; only the secret t (n values) comes back, because GswSk lives on the host.
+int gsw_keygen_device(gsw_ctx *ctx, uint64_t seed, uint64_t first_stream, int sampler, double sigma, int unchecked,
+                      uint32_t *h_t_out, uint32_t *d_pk_matrix_out, void *d_pk_prepared) try {
+    if (!ctx || !h_t_out || !d_pk_prepared || !aligned16(d_pk_prepared)) return fail(GSW_E_INVALID, "bad argument");
+    if (sampler != GSW_SAMPLER_NAIVE && sampler != GSW_SAMPLER_GAUSSIAN) return fail(GSW_E_INVALID, "unknown sampler %d", sampler);
+    if (sampler == GSW_SAMPLER_GAUSSIAN && (!(sigma > 0.0) || sigma > 300.0)) return fail(GSW_E_INVALID, "bad argument (0 < sigma <= 300)");
+    const uint64_t max = ctx->ring.kind == gswk::kRingFp ? (uint64_t)gswk::kFpP - 1 : (uint64_t)ctx->ring.mask;
+    if (!unchecked && max > gswk::kFpP) return fail(GSW_E_INVALID, "assertion failed: max <= P");  // error_sampling.rs:21
+    if (int rc = use_device(ctx)) return rc;
+    const size_t n = (size_t)ctx->n, m = (size_t)ctx->m;
+    auto round = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    std::vector<uint64_t> cum;
+    int kmax = 0;
+    if (sampler == GSW_SAMPLER_GAUSSIAN) gswwire::gaussian_table(sigma, cum, kmax);
+    const size_t o_t = 0, o_e = o_t + round(n * 4), o_bt = o_e + round(m * 4), o_cum = o_bt + round(m * 4),
+                 o_b = o_cum + round(cum.size() * 8 + 8), o_pk = o_b + round(m * n * 4), total = o_pk + round(m * ctx->ld * 4);
+    if (int rc = ensure_small(ctx, total)) return rc;
+    uint8_t *base = (uint8_t *)ctx->small;
+    uint32_t *d_t = (uint32_t *)(base + o_t), *d_e = (uint32_t *)(base + o_e), *d_bt = (uint32_t *)(base + o_bt),
+             *d_b = (uint32_t *)(base + o_b), *d_pk = (uint32_t *)(base + o_pk);
+    uint64_t *d_cum = (uint64_t *)(base + o_cum);
+    hipStream_t st = ctx->stream;
+    // the draws, in the order and on the streams of gsw_impl.rs:18-21: t, e, B
+    HIP_TRY(gswk::launch_fill_uniform(ctx->ring, seed, first_stream, 0, max, d_t, n, st));
+    if (sampler == GSW_SAMPLER_NAIVE) {
+        HIP_TRY(gswk::launch_fill_uniform(ctx->ring, seed, first_stream + 1, 0, gswk::kFpP >> 15, d_e, m, st));  // error_sampling.rs:75-79
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_cum, cum.data(), cum.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(gswk::launch_sample_table(ctx->ring, seed, first_stream + 1, d_cum, (int)cum.size(), kmax, d_e, m, st));
+    }
+    HIP_TRY(gswk::launch_fill_uniform(ctx->ring, seed, first_stream + 2, 0, max, d_b, m * n, st));
+    // b = B t + e (pk.rs:26), pk_matrix = [b | B] (pk.rs:28-36)
+    for (int r0 = 0; r0 < ctx->m; r0 += 32768) {
+        const int cur = ctx->m - r0 < 32768 ? ctx->m - r0 : 32768;
+        HIP_TRY(gswk::launch_row_dot(ctx->ring, d_b, 0, ctx->n, ctx->n, r0, cur, d_t, 1, d_bt + r0, st));
+    }
+    HIP_TRY(gswk::launch_assemble_pk(ctx->ring, d_bt, d_e, d_b, ctx->m, ctx->n, ctx->ld, d_pk, st));
+    gswk::PrepArgs a{};
+    a.src = d_pk;
+    a.dst = (uint8_t *)d_pk_prepared;
+    a.dst_stride = gsw_ctx_pk_prepared_bytes(ctx);
+    a.rows_valid = ctx->m;
+    a.cols_valid = ctx->width;
+    a.ld_src = ctx->ld;
+    a.elems = ctx->words;
+    a.e4 = ctx->ld_r;
+    a.batch = 1;
+    a.packed_tail = ctx->packed_tail;
+    a.layout16 = ctx->gemm_variant >= 4;
+    if (int rc = run_prepare(ctx, a, st)) return rc;
+    if (d_pk_matrix_out)
+        HIP_TRY(hipMemcpyAsync(d_pk_matrix_out, d_pk, m * ctx->ld * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h_t_out, d_t, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GSW_OK;
+}
+GSW_CATCH
+
 int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size_t bytes, int mode, size_t pitch) {
     if (!ctx || !d_src || (bytes & 0xFFFF) || mode < 0 || mode > 1) return fail(GSW_E_INVALID, "bad argument");
     if (!aligned16(d_src)) return fail(GSW_E_INVALID, "source must be 16-byte aligned");

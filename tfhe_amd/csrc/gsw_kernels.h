@@ -117,6 +117,9 @@ hipError_t launch_dense_fixup(const RingDesc &ring, uint32_t *out, const uint32_
 // out[b * nrows + k] = <x_b[row0 + k, 0..cols), vec> mod q
 hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride, int ld, int cols, int row0,
                           int nrows, const uint32_t *vec, int batch, uint32_t *out, hipStream_t stream);
+// pk_matrix = [bt + e | rand_b] with a padded leading dimension (pk.rs:28-38)
+hipError_t launch_assemble_pk(const RingDesc &ring, const uint32_t *bt, const uint32_t *e, const uint32_t *rand_b, int m,
+                              int n, int ld, uint32_t *pk, hipStream_t stream);
 hipError_t launch_fill_uniform(const RingDesc &ring, uint64_t seed, uint64_t stream_id, uint64_t min, uint64_t max,
                                uint32_t *out, size_t count, hipStream_t stream);
 hipError_t launch_random_words(uint64_t seed, uint64_t stream_id, uint32_t *out, int rows, int words, int ld,

@@ -1539,6 +1539,32 @@ hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride
     return hipSuccess;
 }
 
+// pk_matrix = [B t + e | B] (pk.rs:28-38) assembled on the device: row i gets bt[i] + e[i] in column 0, row i of
+// B (m x n, tight) in columns 1..n, zeros in the padding columns up to the leading dimension.
+template <int RING>
+__global__ __launch_bounds__(256) void assemble_pk_kernel(const uint32_t *bt, const uint32_t *e, const uint32_t *rand_b,
+                                                           int m, int n, int ld, uint32_t *pk, uint32_t mask) {
+    const size_t total = (size_t)m * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int i = (int)(idx / (size_t)ld), j = (int)(idx - (size_t)i * ld);
+        uint32_t v = 0u;
+        if (j == 0) v = ring_add<RING>(bt[i], e[i], mask);
+        else if (j <= n) v = rand_b[(size_t)i * n + (j - 1)];
+        pk[idx] = v;
+    }
+}
+
+hipError_t launch_assemble_pk(const RingDesc &ring, const uint32_t *bt, const uint32_t *e, const uint32_t *rand_b, int m,
+                              int n, int ld, uint32_t *pk, hipStream_t stream) {
+    if (m <= 0) return hipSuccess;
+    dim3 grid(grid_for((size_t)m * ld, 256)), block(256);
+    if (ring.kind == kRingFp)
+        hipLaunchKernelGGL(assemble_pk_kernel<kRingFp>, grid, block, 0, stream, bt, e, rand_b, m, n, ld, pk, ring.mask);
+    else
+        hipLaunchKernelGGL(assemble_pk_kernel<kRingZpow2>, grid, block, 0, stream, bt, e, rand_b, m, n, ld, pk, ring.mask);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ sampling and digests
 
 // rnd_ring_elm (error_sampling.rs:20-24): R::from(uniform in [min, max])

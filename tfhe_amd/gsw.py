@@ -352,8 +352,36 @@ class GSW:
         return self.make_sk(t)
 
     # ---- FheScheme ----
-    def keygen(self):
-        """src/gsw/gsw_impl.rs:17-25."""
+    def keygen(self, download: bool = True):
+        """src/gsw/gsw_impl.rs:17-25, on the device (gsw_keygen_device): only the secret t crosses to the host.
+        download=False skips fetching pk_matrix for the host-side PublicKey (it stays usable for encryption)."""
+        eng, L = self.engine, _lib.lib()
+        t = np.empty(self.n, dtype=np.uint32)
+        prepared = eng.alloc(eng.pk_prepared_bytes)
+        d_pk = eng.alloc_u32(self.m * eng.ld) if download else None
+        naive = self.sampler == "naive"
+        sigma = 1.0 if self.sampler in ("naive", "gaussian") else float(self.sampler)
+        first = self._draw + 1
+        self._draw += 3  # t, e, B
+        try:
+            check(L.gsw_keygen_device(eng.handle, self.seed, first, _lib.SAMPLER_NAIVE if naive else _lib.SAMPLER_GAUSSIAN,
+                                      sigma, int(not self.check_max), t.ctypes.data, d_pk.ptr if download else None,
+                                      prepared.ptr))
+        except GswError as exc:
+            if exc.code == _lib.E_INVALID and "max <= P" in exc.message:
+                raise AssertionError(exc.message) from exc  # the reference panics here (error_sampling.rs:21)
+            raise
+        sk = self.make_sk(t)
+        if download:
+            mat = d_pk.download(np.uint32, self.m * eng.ld).reshape(self.m, eng.ld)[:, :self.n + 1].copy()
+            pk = PublicKey(mat[:, 0].copy(), mat, prepared)
+        else:
+            pk = PublicKey(None, None, prepared)
+        return sk, pk
+
+    def keygen_host_assembled(self):
+        """The same key generation with the samples drawn on the device but assembled through the host
+        (GswPk::new as make_pk does it): a cross-check of keygen, draw for draw."""
         mx = self.ring.max_u64()
         try:
             t = self._uniform(0, mx, self.n).download(np.uint32, self.n)
