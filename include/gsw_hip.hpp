@@ -137,6 +137,28 @@ class GSW {
         return {sk, make_pk(rand_b, m_, n_, err, t)};
     }
 
+    // keygen with the samples, b = B t + e, pk_matrix and its prepared form made on the device (gsw_keygen_device):
+    // only t crosses to the host; the public key comes back for the host-side GswPk
+    std::pair<GswSk, GswPk> keygen_device() {
+        std::vector<uint32_t> t((size_t)n_);
+        const int ld = gsw_ctx_ld(ctx_);
+        DeviceBuffer d_pk(ctx_, (size_t)m_ * ld * 4), prepared(ctx_, gsw_ctx_pk_prepared_bytes(ctx_));
+        const uint64_t first = draw_ + 1;
+        draw_ += 3;  // t, e, B
+        check(gsw_keygen_device(ctx_, seed_, first, sampler_ == Sampler::Naive ? GSW_SAMPLER_NAIVE : GSW_SAMPLER_GAUSSIAN,
+                                1.0, check_max_ ? 0 : 1, t.data(), d_pk.u32(), prepared.get()));
+        std::vector<uint32_t> padded((size_t)m_ * ld);
+        d_pk.download(padded.data(), padded.size() * 4);
+        GswPk pk;
+        pk.pk_matrix = DMatrix(m_, n_ + 1);
+        pk.b.resize(m_);
+        for (int i = 0; i < m_; ++i) {
+            pk.b[i] = padded[(size_t)i * ld];
+            for (int j = 0; j <= n_; ++j) pk.pk_matrix(i, j) = padded[(size_t)i * ld + j];
+        }
+        return {make_sk(t), pk};
+    }
+
     GswSk make_sk(const std::vector<uint32_t> &t) const {  // sk.rs:20-28
         GswSk sk;
         sk.t = t;
@@ -234,8 +256,12 @@ class GSW {
         a.download(c.data.data(), c.data.size() * 4);
     }
 
+    // A left operand in the reference's own ciphertext format (0 / 1 off the diagonal) takes the int8-MFMA
+    // contraction, anything else the plain N^3 kernel; set_dense_mode / last_dense_path expose the choice.
     DMatrix mult(const DMatrix &c1, const DMatrix &c2) { return dense_product(c1, c2, false); }  // gsw_impl.rs:104-111
     DMatrix nand(const DMatrix &c1, const DMatrix &c2) { return dense_product(c1, c2, true); }   // gsw_impl.rs:114-123
+    void set_dense_mode(int mode) { check(gsw_ctx_set_dense_fast(ctx_, mode)); }  // 0 never, 1 from 1024 rows, 2 always
+    int last_dense_path() const { return gsw_ctx_last_dense_path(ctx_); }          // 0 plain kernel, 1 MFMA
 
     // the throughput path on device-resident flattened ciphertexts: Pc = G^-1(C1c) * C2c
     CompactCiphertext mult(const CompactCiphertext &c1, const CompactCiphertext &c2) { return gadget(c1, c2, 0); }
@@ -248,6 +274,20 @@ class GSW {
     void eval_circuit(CompactCiphertext &pool, const std::vector<gsw_gate> &gates) {
         check(gsw_eval_circuit(ctx_, pool.buf.u32(), gsw_ctx_compact_elems(ctx_), (uint32_t)pool.batch, gates.data(),
                                gates.size()));
+    }
+
+    // the same with a cache of prepared right operands beside the pool (one entry and one flag per slot)
+    struct PreparedCache {
+        DeviceBuffer buf;
+        std::vector<uint8_t> valid;
+    };
+    PreparedCache make_cache(int slots) {
+        return PreparedCache{DeviceBuffer(ctx_, gsw_ctx_prepared_bytes(ctx_) * (size_t)slots), std::vector<uint8_t>((size_t)slots, 0)};
+    }
+    void eval_circuit(CompactCiphertext &pool, const std::vector<gsw_gate> &gates, PreparedCache &cache) {
+        if ((int)cache.valid.size() != pool.batch) throw std::runtime_error("one cache entry per pool slot");
+        check(gsw_eval_circuit_cached(ctx_, pool.buf.u32(), gsw_ctx_compact_elems(ctx_), (uint32_t)pool.batch,
+                                      cache.buf.get(), cache.valid.data(), gates.data(), gates.size()));
     }
 
     // ---- wire format (layout in gsw_hip.h; the reference has no serialisation) ----

@@ -68,6 +68,12 @@ extern "C" {
     fn gsw_mp_decrypt_batch(ctx: *mut gsw_ctx, h_s: *const u32, d_cc: *const u32, stride: usize, batch: c_int, out: *mut u32) -> c_int;
     fn gsw_matvec(ctx: *mut gsw_ctx, d_mat: *const u32, rows: c_int, cols: c_int, ld: c_int, h_vec: *const u32, d_out: *mut u32) -> c_int;
     fn gsw_add(ctx: *mut gsw_ctx, a: *const u32, b: *const u32, out: *mut u32, count: usize) -> c_int;
+    fn gsw_ctx_set_dense_fast(ctx: *mut gsw_ctx, enable: c_int) -> c_int;
+    fn gsw_ctx_last_dense_path(ctx: *const gsw_ctx) -> c_int;
+    fn gsw_ctx_prepared_bytes(ctx: *const gsw_ctx) -> usize;
+    fn gsw_eval_circuit_cached(ctx: *mut gsw_ctx, d_pool: *mut u32, slot_stride: usize, n_slots: u32, d_prepared_pool: *mut c_void, h_valid: *mut u8, gates: *const gsw_gate, n_gates: usize) -> c_int;
+    fn gsw_keygen_device(ctx: *mut gsw_ctx, seed: u64, first_stream: u64, sampler: c_int, sigma: f64, unchecked: c_int, h_t_out: *mut u32, d_pk_matrix_out: *mut u32, d_pk_prepared: *mut c_void) -> c_int;
+    fn gsw_mul_gadget_batch_static(ctx: *mut gsw_ctx, c1: *const u32, s1: usize, c2: *const u32, s2: usize, out: *mut u32, so: usize, batch: c_int, flags: c_uint) -> c_int;
 }
 
 /// Non-zero status -> the panic the reference would have raised (the library's message carries its text).
@@ -202,6 +208,40 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> GswHip<R, T> {
     pub fn sync(&self) {
         ok(unsafe { gsw_sync(self.ctx) });
     }
+    /// The same gate list with a cache of prepared right operands beside the pool (`gsw_ctx_prepared_bytes`
+    /// per slot, one validity flag per slot): a slot is prepared once until a gate overwrites it.
+    pub fn eval_circuit_cached(&self, d_pool: *mut u32, slots: u32, d_prepared: *mut c_void, valid: &mut [u8], gates: &[gsw_gate]) {
+        assert_eq!(valid.len(), slots as usize, "one flag per slot");
+        let stride = unsafe { gsw_ctx_compact_elems(self.ctx) };
+        ok(unsafe { gsw_eval_circuit_cached(self.ctx, d_pool, stride, slots, d_prepared, valid.as_mut_ptr(), gates.as_ptr(), gates.len()) });
+    }
+    pub fn prepared_bytes(&self) -> usize {
+        unsafe { gsw_ctx_prepared_bytes(self.ctx) }
+    }
+    /// `mul_gadget_batch` for callers that may not allocate device memory (static scratch of the library).
+    pub fn mul_gadget_batch_static(&self, c1: *const u32, c2: *const u32, out: *mut u32, batch: usize, nand: bool) {
+        let stride = unsafe { gsw_ctx_compact_elems(self.ctx) };
+        let flags = if nand { GSW_FLAG_NAND } else { 0 };
+        ok(unsafe { gsw_mul_gadget_batch_static(self.ctx, c1, stride, c2, stride, out, stride, batch as c_int, flags) });
+    }
+    /// Which kernel served the last `mult` / `nand`: 1 = the int8-MFMA contraction (left operand in the reference's
+    /// ciphertext format), 0 = the plain N^3 kernel.  `set_dense_mode(2)` takes the MFMA path at any size.
+    pub fn last_dense_path(&self) -> i32 {
+        unsafe { gsw_ctx_last_dense_path(self.ctx) }
+    }
+    pub fn set_dense_mode(&self, mode: i32) {
+        ok(unsafe { gsw_ctx_set_dense_fast(self.ctx, mode) });
+    }
+    /// keygen (gsw_impl.rs:17-25) with the samples drawn by the library's seeded device generator and everything
+    /// but the secret kept on the GPU: returns t and the m x ld public-key matrix as canonical values.
+    pub fn keygen_on_device(&self, seed: u64, gaussian: bool) -> (Vec<u32>, Vec<u32>) {
+        let ld = unsafe { gsw_ctx_ld(self.ctx) } as usize;
+        let mut t = vec![0u32; self.n];
+        let d_pk = Dev::new(self.ctx, self.m * ld * 4);
+        let prepared = Dev::new(self.ctx, unsafe { gsw_ctx_pk_prepared_bytes(self.ctx) });
+        ok(unsafe { gsw_keygen_device(self.ctx, seed, 1, gaussian as c_int, 1.0, 0, t.as_mut_ptr(), d_pk.u32(), prepared.ptr) });
+        (t, d_pk.to_host(self.m * ld))
+    }
 }
 
 impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
@@ -285,7 +325,9 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
         *c *= constant;
     }
 
-    // gsw_impl.rs:104-111 (default features): any entries, the full N^3 product
+    // gsw_impl.rs:104-111 (default features).  A left operand in the reference's own ciphertext format --
+    // BitDecomp(R * A) + mu * I: 0 / 1 off the diagonal -- runs on the int8-MFMA contraction inside
+    // gsw_mul_dense (3.3 ms against 78 ms at N = 7967); any other entries take the plain N^3 kernel.
     fn mult(&self, a: &Self::Ciphertext, b: &Self::Ciphertext) -> Self::Ciphertext {
         Self::same_size(a, b);
         self.dense_binary(gsw_mul_dense, a, b)

@@ -168,6 +168,36 @@ static void wire_round_trip_and_threshold_hooks() {
     EXPECT(alice.combine_partials(partials) == 1);
 }
 
+// keygen on the device gives the key the host-assembled path gives for the same draws, and the trait-level
+// mult / nand of reference-format ciphertexts take the MFMA path when asked to at this size
+static void device_keygen_and_dense_mfma_path() {
+    GSW<Fp> a(10, 310, Sampler::DiscrGaussian, 21), b(10, 310, Sampler::DiscrGaussian, 21);
+    auto dev = a.keygen_device();
+    auto host = b.keygen();
+    EXPECT(dev.first.t == host.first.t && dev.first.v == host.first.v);
+    EXPECT(dev.second.pk_matrix.data == host.second.pk_matrix.data && dev.second.b == host.second.b);
+    DMatrix c1 = a.encrypt(dev.second, 1), c0 = a.encrypt(dev.second, 0);
+    DMatrix plain = a.mult(c1, c1);  // N = 341: the plain kernel by default
+    EXPECT(a.last_dense_path() == 0 && a.decrypt(dev.first, plain) == 1);
+    a.set_dense_mode(2);
+    DMatrix fast = a.mult(c1, c1);
+    EXPECT(a.last_dense_path() == 1 && fast.data == plain.data);
+    EXPECT(a.decrypt(dev.first, a.mult(c1, c0)) == 0 && a.decrypt(dev.first, a.nand(c1, c1)) == 0);
+    EXPECT(a.decrypt(dev.first, a.nand(c1, c0)) == 1 && a.last_dense_path() == 1);
+    // gates over a pool with the prepared-operand cache: NAND(1, 1) = 0, then NAND(0, 1) = 1
+    CompactCiphertext pool{DeviceBuffer(a.ctx(), gsw_ctx_compact_elems(a.ctx()) * 4 * 4), 4};
+    for (int sl = 0; sl < 2; ++sl) {
+        CompactCiphertext one = a.encrypt_compact(dev.second, 1);
+        std::vector<uint32_t> tmp(gsw_ctx_compact_elems(a.ctx()));
+        one.buf.download(tmp.data(), tmp.size() * 4);
+        check(gsw_memcpy_h2d(a.ctx(), pool.buf.u32() + (size_t)sl * gsw_ctx_compact_elems(a.ctx()), tmp.data(), tmp.size() * 4));
+    }
+    auto cache = a.make_cache(4);
+    a.eval_circuit(pool, {{GSW_GATE_NAND, 0, 1, 2}, {GSW_GATE_NAND, 2, 1, 3}}, cache);
+    EXPECT(a.decrypt(dev.first, pool, 2) == 0 && a.decrypt(dev.first, pool, 3) == 1);
+    EXPECT(cache.valid[1] == 1 && cache.valid[2] == 0 && cache.valid[3] == 0);
+}
+
 static void panics_of_the_reference() {
     GSW<Fp> fhe(2, 62);
     EXPECT(throws_with([&] { fhe.mult(DMatrix(3, 3), DMatrix(4, 4)); }, "different sizes"));       // gsw_impl.rs:105-106
@@ -193,6 +223,7 @@ int main() {
         gadget_path_equals_dense_product_of_flattened_operands();
         nand_gates_over_a_pool();
         wire_round_trip_and_threshold_hooks();
+        device_keygen_and_dense_mfma_path();
         panics_of_the_reference();
     } catch (const std::exception &e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());

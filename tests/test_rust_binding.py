@@ -34,11 +34,13 @@ def _rust_type(t: str) -> str:
 def _header_prototypes():
     text = open(os.path.join(ROOT, "include", "gsw_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    with_defines = text
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)  # preprocessor lines are not part of any prototype
     protos = {}
     for ret, name, params in re.findall(r"([\w\s\*]+?)\b(gsw_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
         plist = [] if params.strip() in ("", "void") else [_c_type(p) for p in params.split(",")]
         protos[name] = (_c_type(ret + " x"), plist)
-    return protos, text
+    return protos, with_defines
 
 
 def _rust_externs():

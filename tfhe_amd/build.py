@@ -24,7 +24,7 @@ def build(force: bool = False) -> str:
     if force or needs_build():
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-               "-o", OUT] + SOURCES
+               "-o", OUT] + SOURCES + ["-ldl"]
         subprocess.check_call(cmd)
     return OUT
 

@@ -3,6 +3,7 @@
 // either runs its HIP kernel or returns an error.
 #include "../../include/gsw_hip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -47,6 +48,40 @@ int fail(int code, const char *fmt, ...) {
 
 struct TimedLaunch {
     hipEvent_t start, stop;
+};
+
+// ROCTx ranges around the batch entry points, so that a rocprofv3 --marker-trace timeline shows which call a
+// kernel belongs to.  Off unless GSW_ROCTX=1; the marker library is looked up at run time, so the engine does
+// not depend on it.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *v = getenv("GSW_ROCTX");
+        if (!v || atoi(v) == 0) return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+struct ScopedRange {
+    bool on;
+    explicit ScopedRange(const char *name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~ScopedRange() {
+        if (on) roctx().pop();
+    }
 };
 
 // Scratch of gsw_mul_gadget_batch_static: the prepared right operands of one chunk.  A file-scope device
@@ -307,9 +342,12 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     if (const char *v = getenv("GSW_GEMM_VARIANT")) ctx->gemm_variant = atoi(v);
 #ifdef GSW_DIAGNOSTIC_BUILDS
     // superseded kernels 0..8 and timing-only builds 10.. (wrong results by design) exist in this library
-    const bool known = ctx->gemm_variant >= 0 && ctx->gemm_variant < 138;
+    bool known = ctx->gemm_variant >= 0 && ctx->gemm_variant < 138;
 #else
-    const bool known = ctx->gemm_variant == 9 || ctx->gemm_variant == 2 || ctx->gemm_variant == 3;
+    bool known = ctx->gemm_variant == 9 || ctx->gemm_variant == 2 || ctx->gemm_variant == 3;
+#endif
+#ifdef GSW_EXP_TALL
+    known = known || ctx->gemm_variant == 10 || ctx->gemm_variant == 11;
 #endif
     if (!known) {
         delete ctx;
@@ -679,6 +717,7 @@ int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t co
 // dimension other than the context's N, a prepared operand beyond the workspace limit -- through the plain
 // dim^3 kernel.  Same results either way (both are the exact product over the ring).
 static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim, int nand) {
+    ScopedRange range("gsw_mul_dense");
     if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
     if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
     if (int rc = use_device(ctx)) return rc;
@@ -907,6 +946,7 @@ struct SlotLists {
 static int mul_batch(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c, size_t stride2,
                      uint32_t *d_out, size_t stride_out, int batch, unsigned flags, uint64_t *d_digests,
                      SlotLists slots = SlotLists()) {
+    ScopedRange range("gsw_mul_gadget_batch");
     if (int rc = check_gemm_common(ctx, d_c1c, stride1, d_out, stride_out, batch, flags)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_c2c) return fail(GSW_E_INVALID, "null right operand");
@@ -1034,6 +1074,7 @@ int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
 // d_cache / h_valid: optional cache of prepared right operands beside the pool (gsw_eval_circuit_cached)
 static int eval_circuit_impl(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, const gsw_gate *h_gates,
                              size_t n_gates, void *d_cache, uint8_t *h_valid) {
+    ScopedRange range("gsw_eval_circuit");
     if (!ctx) return fail(GSW_E_INVALID, "null context");
     if (n_gates == 0) return GSW_OK;
     if (!d_pool || !h_gates) return fail(GSW_E_INVALID, "null operand");
@@ -1295,6 +1336,7 @@ int gsw_random_rbits(gsw_ctx *ctx, uint64_t seed, uint64_t stream, uint32_t *d_r
 
 int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d_rbits, size_t stride_rbits,
                       const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, int batch) {
+    ScopedRange range("gsw_encrypt_batch");
     if (int rc = check_gemm_common(ctx, d_rbits, stride_rbits, d_out, stride_out, batch, 0)) return rc;
     if (batch == 0) return GSW_OK;
     if (!d_pk_prepared || !aligned16(d_pk_prepared) || !d_messages) return fail(GSW_E_INVALID, "bad argument");
@@ -1331,6 +1373,7 @@ int gsw_encrypt_batch_prepared(gsw_ctx *ctx, const void *d_pk_prepared, const ui
 
 static int row_dots(gsw_ctx *ctx, const uint32_t *h_vec, int cols, const uint32_t *d_x, size_t stride, int ld,
                     int row0, int nrows, int batch, std::vector<uint32_t> &host_out) {
+    ScopedRange range("gsw_decrypt");
     const size_t vec_bytes = ((size_t)cols * 4 + 255) & ~(size_t)255;
     const size_t out_bytes = (size_t)batch * nrows * 4;
     if (int rc = ensure_small(ctx, vec_bytes + out_bytes + 16)) return rc;
@@ -1481,6 +1524,7 @@ GSW_CATCH
 // prepared form are all made on the device; only the secret t (n values) comes back, because GswSk lives on the host.
 int gsw_keygen_device(gsw_ctx *ctx, uint64_t seed, uint64_t first_stream, int sampler, double sigma, int unchecked,
                       uint32_t *h_t_out, uint32_t *d_pk_matrix_out, void *d_pk_prepared) try {
+    ScopedRange range("gsw_keygen_device");
     if (!ctx || !h_t_out || !d_pk_prepared || !aligned16(d_pk_prepared)) return fail(GSW_E_INVALID, "bad argument");
     if (sampler != GSW_SAMPLER_NAIVE && sampler != GSW_SAMPLER_GAUSSIAN) return fail(GSW_E_INVALID, "unknown sampler %d", sampler);
     if (sampler == GSW_SAMPLER_GAUSSIAN && (!(sigma > 0.0) || sigma > 300.0)) return fail(GSW_E_INVALID, "bad argument (0 < sigma <= 300)");
