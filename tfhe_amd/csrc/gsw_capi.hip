@@ -732,11 +732,19 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
         // packed left operand (N x ld words), diagonal vector, misfit counter: from the context's scratch
         const size_t packed_bytes = ((size_t)dim * ctx->ld * 4 + 255) & ~(size_t)255;
         const size_t diag_bytes = ((size_t)dim * 4 + 255) & ~(size_t)255;
-        if (int rc = ensure_small(ctx, packed_bytes + diag_bytes + 256)) return rc;
+        const size_t rows_bytes = (((size_t)dim / 256 + 2) * 4 + 255) & ~(size_t)255;
+        if (int rc = ensure_small(ctx, packed_bytes + diag_bytes + 256 + rows_bytes)) return rc;
         uint32_t *packed = (uint32_t *)ctx->small;
         uint32_t *diag = (uint32_t *)((uint8_t *)ctx->small + packed_bytes);
         unsigned long long *d_misfits = (unsigned long long *)((uint8_t *)ctx->small + packed_bytes + diag_bytes);
+        uint32_t *d_rows = (uint32_t *)((uint8_t *)ctx->small + packed_bytes + diag_bytes + 256);
         HIP_TRY(gswk::launch_pack_flat_lhs(ctx->ring, d_c1, dim, ctx->width, ctx->ld, packed, diag, d_misfits, ctx->stream));
+        // first rows of the slabs the product is cut into (see below)
+        const int slab = dim >= 8 * 512 ? 512 : 256;
+        const int entries = (dim + slab - 1) / slab;
+        std::vector<uint32_t> h_rows((size_t)entries, 0u);
+        for (int e = 0; e < entries; ++e) h_rows[e] = (uint32_t)(e * slab + slab <= dim ? e * slab : (dim > slab ? dim - slab : 0));
+        HIP_TRY(hipMemcpyAsync(d_rows, h_rows.data(), h_rows.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         unsigned long long counts[2] = {0, 0};  // misfits, rows with a diagonal term
         HIP_TRY(hipMemcpyAsync(counts, d_misfits, sizeof counts, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -755,34 +763,29 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
             pa.batch = 1;
             pa.packed_tail = packed_tail;
             pa.layout16 = 1;
-            if (int rc = run_prepare(ctx, pa, ctx->stream)) return rc;
             // The kernel places one batch entry per XCD at a time, so the single product is cut into slabs of
-            // `slab` rows that play the part of batch entries (same right operand, stride 0): a launch over the
-            // full slabs, then one over the remaining rows.
-            const int slab = dim >= 8 * 512 ? 512 : 256;
-            const int full = dim / slab;
-            for (int part = 0; part < 2; ++part) {
-                const int row0 = part == 0 ? 0 : full * slab;
-                const int rows = part == 0 ? slab : dim - full * slab;
-                const int entries = part == 0 ? full : 1;
-                if (entries == 0 || rows == 0) continue;
-                gswk::GemmArgs a{};
-                a.lhs = packed + (size_t)row0 * ctx->ld;
-                a.lhs_stride = (size_t)slab * ctx->ld;
-                a.rhs = (const uint8_t *)ctx->ws;
-                a.rhs_stride = 0;
-                a.out = d_out + (size_t)row0 * dim;
-                a.out_stride = (size_t)slab * dim;
-                a.rows = rows;
-                a.e4 = ctx->e4;
-                a.ld_lhs = ctx->ld;
-                a.out_cols = dim;
-                a.ld_out = dim;
-                a.batch = entries;
-                a.mode = gswk::kModeMul;
-                a.packed_tail = packed_tail;
-                if (int rc = run_gemm(ctx, a)) return rc;
-            }
+            // `slab` rows that play the part of batch entries sharing one right operand.  Slot lists with a
+            // stride of one row let every entry start at any row: the last slab is moved up to end at row N
+            // and recomputes the rows it shares with its neighbour (the same values, stored twice).
+            if (int rc = run_prepare(ctx, pa, ctx->stream)) return rc;
+            gswk::GemmArgs a{};
+            a.lhs = packed;
+            a.lhs_stride = (size_t)ctx->ld;
+            a.rhs = (const uint8_t *)ctx->ws;
+            a.rhs_stride = 0;
+            a.out = d_out;
+            a.out_stride = (size_t)dim;
+            a.rows = dim < slab ? dim : slab;
+            a.e4 = ctx->e4;
+            a.ld_lhs = ctx->ld;
+            a.out_cols = dim;
+            a.ld_out = dim;
+            a.batch = entries;
+            a.mode = gswk::kModeMul;
+            a.packed_tail = packed_tail;
+            a.lhs_slot = d_rows;
+            a.out_slot = d_rows;
+            if (int rc = run_gemm(ctx, a)) return rc;
             // the diagonal term diag(d) * C2 and nand's I - P (gsw_impl.rs:114-123), when there is either
             if (counts[1] != 0 || nand)
                 HIP_TRY(gswk::launch_dense_fixup(ctx->ring, d_out, d_c2, diag, dim, nand, ctx->stream));

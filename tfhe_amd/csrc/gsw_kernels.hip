@@ -1863,36 +1863,56 @@ __global__ __launch_bounds__(256) void mul_dense_kernel(const uint32_t *a, const
 // not fit the form (anything but 0 / 1 off the diagonal); dense_fixup_kernel adds the diagonal term and applies
 // nand's I - P (gsw_impl.rs:114-123).
 
+// One workgroup per row: the row's entries are read with coalesced loads (lane = entry), their low bits gathered
+// into a bit string in LDS by wave ballots, and the ell-bit words cut out of that string.
 __global__ __launch_bounds__(256) void pack_flat_lhs_kernel(const uint32_t *c1, int dim, int ell, int words, int ld,
                                                              uint32_t *packed, uint32_t *diag,
                                                              unsigned long long *misfits) {
-    const size_t total = (size_t)dim * ld;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pack_lds[];
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(pack_lds);  // ceil(dim / 64) + 1 words
+    const int tid = threadIdx.x, lane = tid & 63;
     unsigned bad = 0, scaled = 0;  // misfits; rows whose diagonal entry is neither 0 nor 1
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int i = (int)(idx / (size_t)ld), j = (int)(idx - (size_t)i * ld);
-        uint32_t w = 0;
-        if (j < words) {
-            const uint32_t *src = c1 + (size_t)i * dim + (size_t)j * ell;
-            for (int k = 0; k < ell; ++k) {
-                const uint32_t v = src[k];
-                if (j * ell + k == i) {
+    for (int i = blockIdx.x; i < dim; i += gridDim.x) {
+        const uint32_t *src = c1 + (size_t)i * dim;
+        const int chunks = (dim + 63) >> 6;
+        __syncthreads();  // the previous row's words have been cut
+        for (int e0 = (tid >> 6) << 6; e0 < dim; e0 += 256) {  // each wave takes 64 consecutive entries at a time
+            const int e = e0 + lane;
+            uint32_t bit = 0;
+            if (e < dim) {
+                const uint32_t v = src[e];
+                if (e == i) {
                     // the diagonal entry: 0 / 1 stay in B, anything else goes to d
-                    if (v <= 1u) { w |= v << k; diag[i] = 0u; }
+                    if (v <= 1u) { bit = v; diag[i] = 0u; }
                     else { diag[i] = v; ++scaled; }
                 } else {
                     bad += v > 1u;
-                    w |= (v & 1u) << k;
+                    bit = v & 1u;
                 }
             }
+            const unsigned long long mask = __ballot(bit != 0);
+            if (lane == 0) bits[e0 >> 6] = mask;
         }
-        packed[idx] = w;
+        if (tid == 0) bits[chunks] = 0ull;  // the word after the end: reads of the last field may touch it
+        __syncthreads();
+        for (int j = tid; j < ld; j += 256) {
+            uint32_t w = 0;
+            if (j < words) {
+                const unsigned pos = (unsigned)j * (unsigned)ell;  // ell bits from bit `pos` of the string
+                const unsigned q = pos >> 6, r = pos & 63u;
+                unsigned long long field = bits[q] >> r;
+                if (r + (unsigned)ell > 64u) field |= bits[q + 1] << (64u - r);
+                w = (uint32_t)field & (ell >= 32 ? 0xFFFFFFFFu : ((1u << ell) - 1u));
+            }
+            packed[(size_t)i * ld + j] = w;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         bad += (unsigned)__shfl_xor((int)bad, off, 64);
         scaled += (unsigned)__shfl_xor((int)scaled, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         if (bad) atomicAdd(&misfits[0], (unsigned long long)bad);
         if (scaled) atomicAdd(&misfits[1], (unsigned long long)scaled);
     }
@@ -1919,8 +1939,9 @@ hipError_t launch_pack_flat_lhs(const RingDesc &ring, const uint32_t *c1, int di
                                 uint32_t *diag, unsigned long long *misfits, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(misfits, 0, 2 * sizeof(unsigned long long), stream);
     if (e != hipSuccess || dim <= 0) return e;
-    hipLaunchKernelGGL(pack_flat_lhs_kernel, dim3(grid_for((size_t)dim * ld, 256)), dim3(256), 0, stream, c1, dim,
-                       ring.ell, words, ld, packed, diag, misfits);
+    const size_t lds = (((size_t)dim + 63) / 64 + 1) * 8;
+    hipLaunchKernelGGL(pack_flat_lhs_kernel, dim3((unsigned)(dim < 256 * 8 ? dim : 256 * 8)), dim3(256), lds, stream, c1,
+                       dim, ring.ell, words, ld, packed, diag, misfits);
     return hipGetLastError();
 }
 
