@@ -220,6 +220,15 @@ int gsw_encrypt_batch_prepared(gsw_ctx *ctx, const void *d_pk_prepared, const ui
                                const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, void *d_prepared_out,
                                int batch);
 
+/* encrypt (gsw_impl.rs:27-42) with rnd_dmatrix(N, m, 0, 1) of gsw_impl.rs:30 drawn inside the call: the same
+ * ciphertexts, bit for bit, as gsw_random_rbits(seed, stream, R, batch) followed by gsw_encrypt_batch on R, but
+ * the bit matrices (N * ld_r words each) exist only chunk by chunk in the context's workspace, drawn beside the
+ * contraction of the chunk before.  d_prepared_out may be NULL; otherwise it receives the prepared form of
+ * every ciphertext as in gsw_encrypt_batch_prepared. */
+int gsw_encrypt_batch_seeded(gsw_ctx *ctx, const void *d_pk_prepared, uint64_t seed, uint64_t stream,
+                             const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, void *d_prepared_out,
+                             int batch);
+
 /* ---- decrypt (gsw_impl.rs:48-52) and mp_decrypt (gsw_impl.rs:67-84) on compact ciphertexts.
  *      h_s is sk.s = (1, -t) (sk.rs:20-24) on the host; <C[i,:], v> = <Cc[i,:], s>. ---- */
 int gsw_decrypt_batch(gsw_ctx *ctx, const uint32_t *h_s, const uint32_t *d_cc, size_t stride, int batch,

@@ -204,12 +204,12 @@ class GSW {
         DeviceBuffer prepared(ctx_, gsw_ctx_pk_prepared_bytes(ctx_));
         std::vector<uint32_t> pk_rm = pk.pk_matrix.row_major();
         check(gsw_prepare_pk(ctx_, pk_rm.data(), prepared.get()));
-        DeviceBuffer rbits(ctx_, gsw_ctx_rbits_elems(ctx_) * 4), msg(ctx_, 4);
-        check(gsw_random_rbits(ctx_, seed_, ++draw_, rbits.u32(), 1));
+        DeviceBuffer msg(ctx_, 4);
         msg.upload(&message, 4);
         CompactCiphertext out{DeviceBuffer(ctx_, gsw_ctx_compact_elems(ctx_) * 4), 1};
-        check(gsw_encrypt_batch(ctx_, prepared.get(), rbits.u32(), gsw_ctx_rbits_elems(ctx_), msg.u32(),
-                                out.buf.u32(), gsw_ctx_compact_elems(ctx_), 1));
+        // rnd_dmatrix(N, m, 0, 1) of gsw_impl.rs:30 is drawn inside the call by the seeded device generator
+        check(gsw_encrypt_batch_seeded(ctx_, prepared.get(), seed_, ++draw_, msg.u32(), out.buf.u32(),
+                                       gsw_ctx_compact_elems(ctx_), nullptr, 1));
         check(gsw_sync(ctx_));
         return out;
     }

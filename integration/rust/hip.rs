@@ -48,7 +48,6 @@ extern "C" {
     fn gsw_ctx_big_n(ctx: *const gsw_ctx) -> c_int;
     fn gsw_ctx_ld(ctx: *const gsw_ctx) -> c_int;
     fn gsw_ctx_compact_elems(ctx: *const gsw_ctx) -> usize;
-    fn gsw_ctx_rbits_elems(ctx: *const gsw_ctx) -> usize;
     fn gsw_ctx_pk_prepared_bytes(ctx: *const gsw_ctx) -> usize;
     fn gsw_malloc(ctx: *mut gsw_ctx, bytes: usize, d_ptr: *mut *mut c_void) -> c_int;
     fn gsw_free(ctx: *mut gsw_ctx, d_ptr: *mut c_void) -> c_int;
@@ -62,8 +61,7 @@ extern "C" {
     fn gsw_mul_gadget_batch(ctx: *mut gsw_ctx, c1: *const u32, s1: usize, c2: *const u32, s2: usize, out: *mut u32, so: usize, batch: c_int, flags: c_uint) -> c_int;
     fn gsw_eval_circuit(ctx: *mut gsw_ctx, d_pool: *mut u32, slot_stride: usize, n_slots: u32, gates: *const gsw_gate, n_gates: usize) -> c_int;
     fn gsw_prepare_pk(ctx: *mut gsw_ctx, h_pk: *const u32, d_prepared: *mut c_void) -> c_int;
-    fn gsw_random_rbits(ctx: *mut gsw_ctx, seed: u64, stream: u64, d_rbits: *mut u32, batch: c_int) -> c_int;
-    fn gsw_encrypt_batch(ctx: *mut gsw_ctx, pk: *const c_void, rbits: *const u32, stride_r: usize, msgs: *const u32, out: *mut u32, stride_out: usize, batch: c_int) -> c_int;
+    fn gsw_encrypt_batch_seeded(ctx: *mut gsw_ctx, pk: *const c_void, seed: u64, stream: u64, msgs: *const u32, out: *mut u32, stride_out: usize, d_prepared_out: *mut c_void, batch: c_int) -> c_int;
     fn gsw_decrypt_dense(ctx: *mut gsw_ctx, h_v: *const u32, d_c: *const u32, bit: *mut u32) -> c_int;
     fn gsw_mp_decrypt_batch(ctx: *mut gsw_ctx, h_s: *const u32, d_cc: *const u32, stride: usize, batch: c_int, out: *mut u32) -> c_int;
     fn gsw_matvec(ctx: *mut gsw_ctx, d_mat: *const u32, rows: c_int, cols: c_int, ld: c_int, h_vec: *const u32, d_out: *mut u32) -> c_int;
@@ -278,15 +276,13 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
         let big_n = self.big_n();
         let prepared = Dev::new(self.ctx, unsafe { gsw_ctx_pk_prepared_bytes(self.ctx) });
         ok(unsafe { gsw_prepare_pk(self.ctx, Self::to_rows(&pk.pk_matrix).as_ptr(), prepared.ptr) });
-        let rbits = Dev::new(self.ctx, unsafe { gsw_ctx_rbits_elems(self.ctx) } * 4);
         let seed: u64 = rand::rng().random();
         let zero = Dev::from_host(self.ctx, &[0u32]);
         let elems = unsafe { gsw_ctx_compact_elems(self.ctx) };
         let cc = Dev::new(self.ctx, elems * 4);
         let dense = Dev::new(self.ctx, big_n * big_n * 4);
         unsafe {
-            ok(gsw_random_rbits(self.ctx, seed, 1, rbits.u32(), 1));
-            ok(gsw_encrypt_batch(self.ctx, prepared.ptr, rbits.u32(), 0, zero.u32(), cc.u32(), elems, 1));
+            ok(gsw_encrypt_batch_seeded(self.ctx, prepared.ptr, seed, 1, zero.u32(), cc.u32(), elems, std::ptr::null_mut(), 1));
             ok(gsw_bit_decomp(self.ctx, cc.u32(), big_n as c_int, (self.n + 1) as c_int, gsw_ctx_ld(self.ctx), dense.u32()));
         }
         let mut product = Self::from_rows(big_n, big_n, &dense.to_host(big_n * big_n));

@@ -304,19 +304,105 @@ def test_encrypt_matches_oracle(oracle, tfhe_amd):
         _assert_equal(ct.to_dense(1), oracle.bit_decomp_matrix(ring_o, got[1]), "to_dense")
 
 
-def test_device_random_bits_are_the_documented_stream(oracle, tfhe_amd):
-    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
-    n = 4
-    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=77)
-    eng = gsw.engine
+def _stream_words(seed, stream, counters):
+    """The generator of the encryption bits (two rounds of the splitmix64 finaliser over seed, stream and draw
+    number), in numpy, for whole arrays of draw numbers; spot-checked against the oracle's scalar function."""
+    def mix(z):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        key = mix(np.uint64(seed) ^ (np.uint64(stream) * np.uint64(0xD1342543DE82EF95)))
+        return mix(key + counters.astype(np.uint64))
+
+
+@pytest.mark.parametrize("ring_name,n,extra", [("fp", 4, 0), ("fp", 10, 3), ("z32", 5, 0), ("z8", 9, 5), ("fp", 13, 30)])
+def test_device_random_bits_are_the_documented_stream(oracle, tfhe_amd, ring_name, n, extra):
+    """Every word of rnd_dmatrix(N, m, 0, 1) as the device draws it: word (b, row, j) = the low ell bits of draw
+    (b N + row) words + j, the last word of a row cut to the bits m leaves it, padding words zero -- into an
+    aligned buffer (16-byte stores) and into one that is not (word stores)."""
     from tfhe_amd import _lib
-    buf = eng.alloc_u32(eng.rbits_elems * 2)
-    _lib.check(_lib.lib().gsw_random_rbits(eng.handle, 77, 3, buf.ptr, 2))
-    words = buf.download(np.uint32, eng.rbits_elems * 2).reshape(2, eng.big_n, n)
-    for (b, i, j) in [(0, 0, 0), (0, 5, 3), (1, 154, 2), (1, 0, 1)]:
-        expect = oracle.rng_u64(77, 3, (b * eng.big_n + i) * n + j) & 0x7FFFFFFF
-        assert int(words[b, i, j]) == expect
-    assert 0.49 < np.unpackbits(words.view(np.uint8)).mean() * 32 / 31 < 0.51
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    ell = ring_d.ell
+    m = n * ell + extra
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=77)
+    eng = gsw.engine
+    words = -(-m // ell)
+    ld_r = eng.rbits_elems // eng.big_n
+    batch = 3
+    draws = np.arange(batch * eng.big_n * words, dtype=np.uint64).reshape(batch, eng.big_n, words)
+    expect = (_stream_words(77, 3, draws) & np.uint64((1 << ell) - 1)).astype(np.uint32)
+    last_bits = m - (words - 1) * ell
+    expect[:, :, -1] &= np.uint32((1 << last_bits) - 1)
+    for (b, i, j) in [(0, 0, 0), (1, 5, 1), (2, eng.big_n - 1, words - 2)]:
+        assert int(expect[b, i, j]) == oracle.rng_u64(77, 3, (b * eng.big_n + i) * words + j) & ((1 << ell) - 1)
+    for shift in (0, 1):  # destination 16-byte aligned / 4 bytes past it
+        buf = eng.alloc_u32(eng.rbits_elems * batch + 4)
+        _lib.check(_lib.lib().gsw_memset_zero(eng.handle, buf.ptr, 4 * (eng.rbits_elems * batch + 4)))
+        _lib.check(_lib.lib().gsw_random_rbits(eng.handle, 77, 3, buf.ptr + 4 * shift, batch))
+        eng.sync()
+        raw = buf.download(np.uint32, eng.rbits_elems * batch + 4)
+        got = raw[shift:shift + eng.rbits_elems * batch].reshape(batch, eng.big_n, ld_r)
+        _assert_equal(got[:, :, :words], expect, f"random words {ring_name} n={n} m={m} shift={shift}")
+        assert not got[:, :, words:].any() and not raw[:shift].any() and not raw[shift + eng.rbits_elems * batch:].any()
+    if extra == 0 and ell > 8:
+        density = np.unpackbits(expect.view(np.uint8)).mean() * 32 / ell
+        assert 0.49 < density < 0.51
+
+
+@pytest.mark.parametrize("ring_name,n,extra,batch,tight", [("fp", 10, 0, 70, False), ("fp", 10, 3, 9, True),
+                                                           ("z32", 7, 0, 45, False), ("z8", 33, 2, 5, False)])
+def test_seeded_encryption_equals_drawn_bits_then_encrypt(oracle, tfhe_amd, ring_name, n, extra, batch, tight):
+    """gsw_encrypt_batch_seeded (bits drawn chunk by chunk beside the contraction, never stored whole) gives the
+    ciphertexts of gsw_random_rbits + gsw_encrypt_batch bit for bit -- and therefore the oracle's, whose encryption
+    of given bits the test above pins -- and the prepared forms gsw_prepare_rhs makes of them; they decrypt."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    m = n * ring_d.ell + extra
+    gsw = tfhe_amd.GSW(ring_d, n, m, seed=31, check_max=ring_name != "z32")
+    eng = gsw.engine
+    sk, pk = gsw.keygen()
+    rng = np.random.default_rng(batch)
+    msgs = rng.integers(0, 2, size=batch).astype(np.uint32)
+    d_m = eng.alloc_u32(batch)
+    d_m.upload(msgs)
+    d_r = eng.alloc_u32(eng.rbits_elems * batch)
+    _lib.check(L.gsw_random_rbits(eng.handle, 31, 9, d_r.ptr, batch))
+    want = tfhe_amd.Ciphertext(eng, batch)
+    _lib.check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, want.ptr, want.stride,
+                                   batch))
+    want_prep = eng.alloc(eng.prepared_bytes * batch)
+    _lib.check(L.gsw_prepare_rhs(eng.handle, want.ptr, want.stride, want_prep.ptr, batch))
+    if tight:  # room for one bit matrix per workspace half: chunks of one encryption
+        limit = max(2 * 4 * eng.rbits_elems, eng.prepared_bytes)
+        assert limit < 4 * 4 * eng.rbits_elems
+        _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, limit))
+    got = tfhe_amd.Ciphertext(eng, batch)
+    got_prep = eng.alloc(eng.prepared_bytes * batch)
+    _lib.check(L.gsw_encrypt_batch_seeded(eng.handle, pk.prepared.ptr, 31, 9, d_m.ptr, got.ptr, got.stride, got_prep.ptr,
+                                          batch))
+    eng.sync()
+    _assert_equal(got.to_compact(), want.to_compact(), f"seeded encryption {ring_name} n={n} m={m} batch={batch}")
+    assert np.array_equal(got_prep.download(np.uint8, eng.prepared_bytes * batch),
+                          want_prep.download(np.uint8, eng.prepared_bytes * batch))
+    assert gsw.decrypt_batch(sk, got).tolist() == msgs.tolist()
+    # without the prepared output, twice in a row on the same workspace, and a product right behind it on the
+    # same streams (its preparation reuses the workspace the bits lived in)
+    for _ in range(2):
+        again = tfhe_amd.Ciphertext(eng, batch)
+        _lib.check(L.gsw_encrypt_batch_seeded(eng.handle, pk.prepared.ptr, 31, 9, d_m.ptr, again.ptr, again.stride, None,
+                                              batch))
+    prod = gsw.mult(again, got)
+    og = oracle.GSW(ring_o, n, m)
+    c = want.to_compact()
+    _assert_equal(again.to_compact(), c, "second seeded run")
+    _assert_equal(prod.to_compact()[batch - 1], og.mul_gadget(c[batch - 1], c[batch - 1]), "product after encryption")
+    # through the Python front end: the same stream numbering as explicit bits would get
+    assert gsw.decrypt_batch(sk, gsw.encrypt_batch(pk, msgs.tolist())).tolist() == msgs.tolist()
 
 
 def test_mp_decrypt(oracle, tfhe_amd):

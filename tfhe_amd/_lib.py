@@ -81,6 +81,7 @@ SIGNATURES = {
     "gsw_eval_circuit": (_i, [_vp, _vp, _sz, _u32, C.POINTER(Gate), _sz]),
     "gsw_eval_circuit_cached": (_i, [_vp, _vp, _sz, _u32, _vp, _vp, C.POINTER(Gate), _sz]),
     "gsw_encrypt_batch_prepared": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _i]),
+    "gsw_encrypt_batch_seeded": (_i, [_vp, _vp, _u64, _u64, _vp, _vp, _sz, _vp, _i]),
     "gsw_prepare_pk": (_i, [_vp, _vp, _vp]),
     "gsw_pack_rbits": (_i, [_vp, _vp, _vp]),
     "gsw_random_rbits": (_i, [_vp, _u64, _u64, _vp, _i]),

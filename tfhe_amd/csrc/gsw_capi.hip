@@ -1372,6 +1372,72 @@ int gsw_encrypt_batch_prepared(gsw_ctx *ctx, const void *d_pk_prepared, const ui
     return prepare_rhs_on(ctx, d_out, stride_out, d_prepared_out, batch, ctx->stream);
 }
 
+// Encryption from a seed: the random bit matrices never exist as a whole.  They are drawn chunk by chunk into the two
+// halves of the workspace on the auxiliary stream, beside the contraction of the chunk before (the generator is
+// VALU- and HBM-bound, the contraction MFMA-bound); with d_prepared_out the fresh ciphertexts are also put into
+// prepared form there, behind the next chunk's bits.  Same events and hand-offs as the product pipeline.
+int gsw_encrypt_batch_seeded(gsw_ctx *ctx, const void *d_pk_prepared, uint64_t seed, uint64_t stream_id,
+                             const uint32_t *d_messages, uint32_t *d_out, size_t stride_out, void *d_prepared_out,
+                             int batch) try {
+    ScopedRange range("gsw_encrypt_batch_seeded");
+    if (!ctx) return fail(GSW_E_INVALID, "null context");
+    if (batch < 0) return fail(GSW_E_INVALID, "negative batch");
+    if (batch == 0) return GSW_OK;
+    if (!d_pk_prepared || !aligned16(d_pk_prepared) || !d_messages || !d_out || !aligned16(d_out))
+        return fail(GSW_E_INVALID, "null or unaligned argument");
+    if (d_prepared_out && !aligned16(d_prepared_out)) return fail(GSW_E_INVALID, "unaligned prepared output");
+    if (stride_out < gsw_ctx_compact_elems(ctx) && batch > 1)
+        return fail(GSW_E_INVALID, "output stride %zu smaller than one ciphertext (%zu)", stride_out,
+                    gsw_ctx_compact_elems(ctx));
+    if (int rc = use_device(ctx)) return rc;
+    const size_t elems = gsw_ctx_rbits_elems(ctx), bytes = elems * 4, prep = gsw_ctx_prepared_bytes(ctx);
+    size_t chunk = 32;
+    if (chunk > ctx->ws_limit / (2 * bytes)) chunk = ctx->ws_limit / (2 * bytes);
+    if (chunk < 1) chunk = 1;  // one bit matrix per half is the least the pipeline can work with
+    if (chunk > (size_t)batch) chunk = (size_t)batch;
+    std::vector<std::pair<size_t, int>> chunks;  // a short first chunk: its bits are the only ones nothing hides
+    for (size_t b0 = 0, step = chunk >= 16 ? chunk / 4 : chunk; b0 < (size_t)batch; b0 += step, step = chunk)
+        chunks.emplace_back(b0, (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step));
+    if (int rc = ensure_workspace(ctx, 2 * chunk * bytes)) return rc;
+    const int last_bits = ctx->m - (ctx->words - 1) * ctx->ring.ell;
+    auto draw = [&](size_t k) -> int {  // the bits of chunk k, on the auxiliary stream, into half k & 1
+        const int half = (int)(k & 1);
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));  // chunk k - 2 has read them
+        HIP_TRY(gswk::launch_random_words(seed, stream_id, (uint32_t *)ctx->ws + (size_t)half * chunk * elems,
+                                          ctx->big_n, ctx->words, ctx->ld_r, ctx->ring.ell, last_bits, chunks[k].second,
+                                          elems, ctx->aux_stream, chunks[k].first));
+        HIP_TRY(hipEventRecord(ctx->ev_prep[half], ctx->aux_stream));
+        return GSW_OK;
+    };
+    auto body = [&]() -> int {
+        HIP_TRY(hipEventRecord(ctx->ev_entry, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_entry, 0));
+        if (int rc = draw(0)) return rc;
+        for (size_t k = 0; k < chunks.size(); ++k) {
+            const size_t b0 = chunks[k].first;
+            const int cur = chunks[k].second, half = (int)(k & 1);
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_prep[half], 0));
+            if (int rc = gsw_encrypt_batch(ctx, d_pk_prepared, (const uint32_t *)ctx->ws + (size_t)half * chunk * elems, elems,
+                                           d_messages + b0, d_out + b0 * stride_out, stride_out, cur))
+                return rc;
+            HIP_TRY(hipEventRecord(ctx->ev_gemm[half], ctx->stream));
+            if (k + 1 < chunks.size())
+                if (int rc = draw(k + 1)) return rc;
+            if (d_prepared_out) {
+                HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_gemm[half], 0));
+                if (int rc = prepare_rhs_on(ctx, d_out + b0 * stride_out, stride_out, (uint8_t *)d_prepared_out + b0 * prep,
+                                            cur, ctx->aux_stream))
+                    return rc;
+            }
+        }
+        return GSW_OK;
+    };
+    const int rc = body();
+    join_aux(ctx);  // the last preparations (and, after a failure, whatever was enqueued) before the caller's next call
+    return rc;
+}
+GSW_CATCH
+
 // ---- decrypt ----
 
 static int row_dots(gsw_ctx *ctx, const uint32_t *h_vec, int cols, const uint32_t *d_x, size_t stride, int ld,

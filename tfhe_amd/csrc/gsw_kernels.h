@@ -122,8 +122,10 @@ hipError_t launch_assemble_pk(const RingDesc &ring, const uint32_t *bt, const ui
                               int n, int ld, uint32_t *pk, hipStream_t stream);
 hipError_t launch_fill_uniform(const RingDesc &ring, uint64_t seed, uint64_t stream_id, uint64_t min, uint64_t max,
                                uint32_t *out, size_t count, hipStream_t stream);
+// entry b of the call draws as entry first_entry + b of one long batch would
 hipError_t launch_random_words(uint64_t seed, uint64_t stream_id, uint32_t *out, int rows, int words, int ld,
-                               int ell, int last_bits, int batch, size_t stride, hipStream_t stream);
+                               int ell, int last_bits, int batch, size_t stride, hipStream_t stream,
+                               size_t first_entry = 0);
 hipError_t launch_sample_table(const RingDesc &ring, uint64_t seed, uint64_t stream_id, const uint64_t *cum,
                                int table_len, int kmax, uint32_t *out, size_t count, hipStream_t stream);
 // counter calibration (see stream_read_kernel)

@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t gadget_entry(int row, int col, int ell, uint
     return ring_from_u64<RING>(1ull << (row - j * ell), mask);
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -2068,32 +2068,57 @@ hipError_t launch_fill_uniform(const RingDesc &ring, uint64_t seed, uint64_t str
 }
 
 // rnd_dmatrix(N, m, 0, 1) (gsw_impl.rs:30) as packed words: word (b, row, j) = ell uniform bits from
-// draw number (b*rows + row)*words + j (the last word keeps only last_bits of them when ell does not
-// divide m); padding words j >= words are zero.
-__global__ void random_words_kernel(uint64_t seed, uint64_t stream_id, uint32_t *out, int rows, int words, int ld,
-                                    int ell, int last_bits, int batch, size_t stride) {
-    const size_t per = (size_t)rows * ld;
-    const size_t total = per * batch;
-    const uint32_t keep = ell >= 32 ? 0xFFFFFFFFu : ((1u << ell) - 1u);
-    const uint32_t keep_last = last_bits >= 32 ? 0xFFFFFFFFu : ((1u << last_bits) - 1u);
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = idx / per, rem = idx - b * per;
-        const size_t row = rem / ld;
-        const int j = (int)(rem - row * ld);
-        uint32_t w = 0;
-        if (j < words)
-            w = (uint32_t)rng_u64(seed, stream_id, (b * rows + row) * words + j) & (j == words - 1 ? keep_last : keep);
-        out[b * stride + rem] = w;
+// draw number ((first_entry + b)*rows + row)*words + j (the last word keeps only last_bits of them when ell
+// does not divide m); padding words j >= words are zero.  A thread makes four consecutive words of a row and
+// stores them as 16 bytes (VEC) or one by one (a destination that is not 16-byte aligned); the batch entry is
+// blockIdx.y, so the index arithmetic stays in 32 bits.  `key` is the generator's stream key, mixed on the host.
+template <bool VEC>
+__global__ __launch_bounds__(256) void random_words_kernel(uint64_t key, uint32_t *out, int rows, int words, int ld,
+                                                           uint32_t keep, uint32_t keep_last, size_t stride,
+                                                           size_t first_entry) {
+    const uint32_t ld4 = (uint32_t)ld >> 2;
+    const uint32_t quads = (uint32_t)rows * ld4;
+    uint32_t *dst = out + (size_t)blockIdx.y * stride;
+    const uint64_t row0 = (first_entry + blockIdx.y) * (uint64_t)rows;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < quads; q += gridDim.x * 256u) {
+        const uint32_t row = q / ld4;
+        const int j0 = (int)(q - row * ld4) * 4;
+        const uint64_t draw = (row0 + row) * (uint64_t)words + (uint64_t)j0;
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = j0 + i;
+            w[i] = j < words ? (uint32_t)mix64(key + draw + (uint64_t)i) & (j == words - 1 ? keep_last : keep) : 0u;
+        }
+        uint32_t *p = dst + (size_t)row * ld + j0;
+        if (VEC) {
+            *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] = w[i];
+        }
     }
 }
 
 hipError_t launch_random_words(uint64_t seed, uint64_t stream_id, uint32_t *out, int rows, int words, int ld, int ell,
-                               int last_bits, int batch, size_t stride, hipStream_t stream) {
-    const size_t total = (size_t)rows * ld * batch;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(random_words_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, seed, stream_id, out,
-                       rows, words, ld, ell, last_bits, batch, stride);
+                               int last_bits, int batch, size_t stride, hipStream_t stream, size_t first_entry) {
+    if (rows <= 0 || batch <= 0) return hipSuccess;
+    if (ld <= 0 || (ld & 3) || words > ld || (size_t)rows * (size_t)ld >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    const uint64_t key = mix64(seed ^ (stream_id * 0xD1342543DE82EF95ull));
+    const uint32_t keep = ell >= 32 ? 0xFFFFFFFFu : ((1u << ell) - 1u);
+    const uint32_t keep_last = last_bits >= 32 ? 0xFFFFFFFFu : ((1u << last_bits) - 1u);
+    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && (stride & 3u) == 0;
+    const unsigned blocks_x = grid_for((size_t)rows * (size_t)(ld / 4), 256);
+    for (int b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.y is a 16-bit quantity
+        const int cur = batch - b0 < 65535 ? batch - b0 : 65535;
+        dim3 grid(blocks_x, (unsigned)cur), block(256);
+        if (vec)
+            hipLaunchKernelGGL(random_words_kernel<true>, grid, block, 0, stream, key, out + (size_t)b0 * stride, rows,
+                               words, ld, keep, keep_last, stride, first_entry + (size_t)b0);
+        else
+            hipLaunchKernelGGL(random_words_kernel<false>, grid, block, 0, stream, key, out + (size_t)b0 * stride, rows,
+                               words, ld, keep, keep_last, stride, first_entry + (size_t)b0);
+    }
     return hipGetLastError();
 }
 

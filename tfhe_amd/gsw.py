@@ -408,13 +408,6 @@ class GSW:
             raise ValueError("public key was built for different (n, m)")
         msgs = np.ascontiguousarray(messages, dtype=np.uint32)
         batch = msgs.size
-        d_r = eng.alloc_u32(eng.rbits_elems * batch)
-        if rbits is None:
-            check(L.gsw_random_rbits(eng.handle, self.seed, self._stream(), d_r.ptr, batch))
-        else:
-            rbits = np.ascontiguousarray(rbits, dtype=np.uint8).reshape(batch, eng.big_n, self.m)
-            for b in range(batch):
-                check(L.gsw_pack_rbits(eng.handle, rbits[b].ctypes.data, d_r.ptr + 4 * eng.rbits_elems * b))
         d_m = eng.alloc_u32(batch)
         d_m.upload(msgs)
         if out is None:
@@ -424,14 +417,25 @@ class GSW:
                 raise ValueError(f"entries {slot}..{slot + batch - 1} do not fit a batch of {out.batch}")
             ct, dst = out, out.entry_ptr(slot)
         target = ct.ptr if dst is None else dst
-        if cache is None:
-            check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, target, ct.stride,
-                                      batch))
+        if cache is not None and slot + batch > cache.slots:
+            raise ValueError("the prepared-operand cache is shorter than the pool range written")
+        prepared_out = None if cache is None else cache.entry_ptr(slot)
+        if rbits is None:
+            # the bits are drawn inside the call, chunk by chunk beside the contraction: no N x m matrix per entry
+            check(L.gsw_encrypt_batch_seeded(eng.handle, pk.prepared.ptr, self.seed, self._stream(), d_m.ptr, target,
+                                             ct.stride, prepared_out, batch))
         else:
-            if slot + batch > cache.slots:
-                raise ValueError("the prepared-operand cache is shorter than the pool range written")
-            check(L.gsw_encrypt_batch_prepared(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, target,
-                                               ct.stride, cache.entry_ptr(slot), batch))
+            d_r = eng.alloc_u32(eng.rbits_elems * batch)
+            rbits = np.ascontiguousarray(rbits, dtype=np.uint8).reshape(batch, eng.big_n, self.m)
+            for b in range(batch):
+                check(L.gsw_pack_rbits(eng.handle, rbits[b].ctypes.data, d_r.ptr + 4 * eng.rbits_elems * b))
+            if cache is None:
+                check(L.gsw_encrypt_batch(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr, target,
+                                          ct.stride, batch))
+            else:
+                check(L.gsw_encrypt_batch_prepared(eng.handle, pk.prepared.ptr, d_r.ptr, eng.rbits_elems, d_m.ptr,
+                                                   target, ct.stride, prepared_out, batch))
+        if cache is not None:
             cache.valid[slot:slot + batch] = 1
         eng.sync()
         return ct
