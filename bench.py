@@ -199,7 +199,9 @@ def main():
 def run(args, gsw, ring, n, batch, pool_default, variant, rank, world, dev, rehearsal):
     eng, L = gsw.engine, _lib.lib()
     big_n, ld, ct = eng.big_n, eng.ld, eng.compact_elems
-    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, max(min(batch, 256) * eng.prepared_bytes, eng.prepared_bytes)))
+    # room for two pipeline chunks of 128 prepared right operands (8.6 GB at n = 512), and never less than 256 MiB:
+    # small shapes then run as one preparation and one contraction launch instead of a launch-bound pipeline
+    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, max(min(batch, 256) * eng.prepared_bytes, 256 << 20)))
 
     # resident pool of synthetic compact ciphertexts: i.i.d. uniform in [0, q), padding columns zero
     pool = args.pool or pool_default or min(2 * batch, 2048)

@@ -903,6 +903,9 @@ int gsw_mul_gadget_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1,
                         nullptr);
 }
 
+// least amount of staged data (prepared right operands, random bit matrices) that is worth a pipeline stage of its own
+constexpr size_t kMinChunkBytes = (size_t)64 << 20;
+
 // How a batch is cut into chunks of prepared right operands: pipelined over the two workspace halves (the
 // preparation of chunk k+1 beside the contraction of chunk k) or one after another on one stream.
 struct ChunkPlan {
@@ -917,6 +920,9 @@ static ChunkPlan plan_chunks(const gsw_ctx *ctx, int batch) {
     size_t pipe_chunk = (size_t)ctx->overlap_chunk;
     // shorter batches (one level of a circuit) still get four chunks to overlap, down to 32 products
     if (pipe_chunk && (size_t)batch < 4 * pipe_chunk) pipe_chunk = (size_t)batch / 4 > 32 ? (size_t)batch / 4 : 32;
+    // small shapes: a chunk whose preparation is shorter than the launches and event hand-offs that pipelining adds
+    // is not worth cutting off -- a chunk holds at least kMinChunkBytes of prepared operands (n = 10: 1 366 products)
+    if (pipe_chunk && pipe_chunk * prep < kMinChunkBytes) pipe_chunk = (kMinChunkBytes + prep - 1) / prep;
     if (pipe_chunk > ctx->ws_limit / (2 * prep)) pipe_chunk = ctx->ws_limit / (2 * prep);
     if (pipe_chunk >= 1 && (size_t)batch > pipe_chunk) {
         plan.pipelined = true;
@@ -1392,11 +1398,13 @@ int gsw_encrypt_batch_seeded(gsw_ctx *ctx, const void *d_pk_prepared, uint64_t s
     if (int rc = use_device(ctx)) return rc;
     const size_t elems = gsw_ctx_rbits_elems(ctx), bytes = elems * 4, prep = gsw_ctx_prepared_bytes(ctx);
     size_t chunk = 32;
+    if (chunk * bytes < kMinChunkBytes) chunk = (kMinChunkBytes + bytes - 1) / bytes;  // small shapes: fewer, longer launches
     if (chunk > ctx->ws_limit / (2 * bytes)) chunk = ctx->ws_limit / (2 * bytes);
     if (chunk < 1) chunk = 1;  // one bit matrix per half is the least the pipeline can work with
     if (chunk > (size_t)batch) chunk = (size_t)batch;
     std::vector<std::pair<size_t, int>> chunks;  // a short first chunk: its bits are the only ones nothing hides
-    for (size_t b0 = 0, step = chunk >= 16 ? chunk / 4 : chunk; b0 < (size_t)batch; b0 += step, step = chunk)
+    const bool short_first = chunk >= 16 && (chunk / 4) * bytes >= kMinChunkBytes / 4;
+    for (size_t b0 = 0, step = short_first ? chunk / 4 : chunk; b0 < (size_t)batch; b0 += step, step = chunk)
         chunks.emplace_back(b0, (int)((size_t)batch - b0 < step ? (size_t)batch - b0 : step));
     if (int rc = ensure_workspace(ctx, 2 * chunk * bytes)) return rc;
     const int last_bits = ctx->m - (ctx->words - 1) * ctx->ring.ell;
