@@ -538,24 +538,37 @@ class GSW:
 
     GATE_OPS = {"mult": 0, "nand": 1, "add": 2, "mult_const": 3}
 
+    @classmethod
+    def encode_gates(cls, gates) -> np.ndarray:
+        """(op, a, b, out) tuples -> the (len, 4) uint32 array that is the C ABI's gsw_gate list; a list that is
+        evaluated many times is encoded once."""
+        if isinstance(gates, np.ndarray):
+            if gates.dtype != np.uint32 or gates.ndim != 2 or gates.shape[1] != 4:
+                raise ValueError("an encoded gate list is a (len, 4) uint32 array")
+            return np.ascontiguousarray(gates)
+        gates = list(gates)
+        arr = np.empty((len(gates), 4), dtype=np.uint32)
+        for i, (op, ga, gb, out) in enumerate(gates):
+            if op not in cls.GATE_OPS:
+                raise ValueError(f"unknown gate op {op!r}")
+            arr[i] = (cls.GATE_OPS[op], ga, gb, out)
+        return arr
+
     def eval_circuit(self, pool: Ciphertext, gates, cache: Optional[PreparedCache] = None) -> None:
         """Apply (op, a, b, out) gates over the slots of `pool` (a batch of resident ciphertexts), in list
         order: op is "mult" / "nand" / "add" / "mult_const" (src/gsw/gsw_impl.rs:87-123; for mult_const
-        b is the constant).  Independent consecutive products run as one batched contraction.  With a
-        PreparedCache every slot is put into prepared form at most once until it is overwritten."""
-        gates = list(gates)
-        arr = (_lib.Gate * len(gates))()
-        for i, (op, ga, gb, out) in enumerate(gates):
-            if op not in self.GATE_OPS:
-                raise ValueError(f"unknown gate op {op!r}")
-            arr[i] = _lib.Gate(self.GATE_OPS[op], int(ga), int(gb), int(out))
+        b is the constant).  `gates` is a sequence of such tuples or the array encode_gates made of one.
+        Independent consecutive products run as one batched contraction.  With a PreparedCache every slot is
+        put into prepared form at most once until it is overwritten."""
+        arr = self.encode_gates(gates)
+        gate_ptr = arr.ctypes.data_as(C.POINTER(_lib.Gate))
         if cache is None:
-            check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, arr, len(gates)))
+            check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, gate_ptr, len(arr)))
             return
         if cache.slots != pool.batch:
             raise ValueError("the prepared-operand cache must have one entry per pool slot")
         check(_lib.lib().gsw_eval_circuit_cached(self.engine.handle, pool.ptr, pool.stride, pool.batch, cache.buf.ptr,
-                                                 cache.valid.ctypes.data, arr, len(gates)))
+                                                 cache.valid.ctypes.data, gate_ptr, len(arr)))
 
     # ---- the reference's dense operations on arbitrary matrices ----
     def _dense_binary(self, fn, a, b) -> np.ndarray:

@@ -51,6 +51,7 @@ def main():
         src, dst = (0, chains) if lvl % 2 == 0 else (chains, 0)
         gates += [("mult", src + c, chains * (2 + lvl) + c, dst + c) for c in range(chains)]
     final = 0 if depth % 2 == 0 else chains
+    gates = gsw.encode_gates(gates)  # the C ABI's gate array, made once: the timed runs hand it over as it is
 
     gsw.eval_circuit(pool, gates)  # acc <- mult(acc, fresh_level), level after level
     eng.sync()
