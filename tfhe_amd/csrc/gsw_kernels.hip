@@ -380,12 +380,110 @@ constexpr int pipe_lds_bytes() { return kPipeBuffers * (WAVES * 1024 + kStageEle
 // LDS load.  Right-operand fragments of a stage: [step p][limb l][column group cg] (packed tail:
 // [p][cg], MFMA column 8 l + c of the 32 carrying limb l of column c).
 
+// One wave's share of a digest: wave reduction, then one atomic (the sum mod 2^64 does not depend on the order
+// of arrival).  The digest's odd constant factor is applied here, once per wave.
+__device__ __forceinline__ void digest_commit(const GemmArgs &p, int b, int lane, unsigned long long dig) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)dig, off, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(dig >> 32), off, 64);
+        dig += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) atomicAdd(&p.digests[b], dig * 0x9E3779B97F4A7C15ull);
+}
+
+// sum_l 2^(8 l) a_l as a canonical ring element, for limb sums a_l < 2^28 (at most 255 * K, K <= 2^20)
+template <int RING>
+__device__ __forceinline__ uint32_t combine_limb_sums(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t mask) {
+    if (RING == kRingZpow2) return (a0 + (a1 << 8) + (a2 << 16) + (a3 << 24)) & mask;  // pow2_ring.rs:97-103
+    const uint64_t v = (uint64_t)a0 + ((uint64_t)a1 << 8) + ((uint64_t)a2 << 16) + ((uint64_t)a3 << 24);  // < 2^53
+    uint32_t x = ((uint32_t)v & kFpP) + (uint32_t)(v >> 31);  // 2^31 = 1 mod p; x < 2^31 + 2^22
+    x = (x & kFpP) + (x >> 31);                               // x <= p
+    return min(x, x - kFpP);                                  // p -> 0; below p the difference wraps above x
+}
+
+// Epilogue of a wave whose 16 RG rows x 32 columns all lie inside the product and hold no gadget entry (the one
+// non-zero of a row of G sits in column row / ell): every element is stored, nothing is tested per element,
+// nand is a plain negation and the encryption addend meets only zeros.  Same results as the general epilogue
+// below, which handles the edge tiles, the packed tail tile and the tiles that cross the gadget's diagonal band.
+template <int RING, int RG, bool NEGATE, bool DIGEST>
+__device__ __forceinline__ void gemm16_epilogue_interior(const GemmArgs &p, const TileCtx &c, int tile_rows,
+                                                         const v4i (&acc)[RG][8], const uint32_t (&pop)[RG]) {
+    const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
+    uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
+    const int row0 = c.mt * tile_rows + c.wave * (16 * RG) + 4 * quad;
+    const int col0 = c.nt * kTileCols + c16;
+    unsigned long long dig = 0;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * quad + r;  // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
+            const uint32_t bias =
+                128u * (uint32_t)(__shfl((int)pop[rg], rr, 64) + __shfl((int)pop[rg], rr + 32, 64));
+            const size_t idx = (size_t)(row0 + rg * 16 + r) * p.ld_out + col0;
+            uint32_t *dst = out + idx;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                uint32_t val = combine_limb_sums<RING>((uint32_t)acc[rg][0 + cg][r] + bias, (uint32_t)acc[rg][2 + cg][r] + bias,
+                                                       (uint32_t)acc[rg][4 + cg][r] + bias, (uint32_t)acc[rg][6 + cg][r] + bias,
+                                                       c.mask);
+                if (NEGATE) {
+                    if (RING == kRingFp) {
+                        const uint32_t t = kFpP - val;  // 0 -> p -> 0
+                        val = min(t, t - kFpP);
+                    } else {
+                        val = (0u - val) & c.mask;
+                    }
+                }
+                dst[cg * 16] = val;
+                if (DIGEST) {
+                    const unsigned w = 2u * ((unsigned)idx + 16u * cg) + 1u;
+                    dig += (unsigned long long)val * w + w;
+                }
+            }
+        }
+    }
+    if (DIGEST) digest_commit(p, c.b, lane, dig);
+}
+
 template <int RING, bool PACKED, int RG = 4>
 __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
                                                 const v4i (&acc)[RG][PACKED ? 2 : 8], const uint32_t (&pop)[RG]) {
     const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
     uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
+#ifdef GSW_EXP_NOEPI
+    {   // timing experiment (wrong results): what the kernel costs without its epilogue
+        int x = 0;
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int f = 0; f < (PACKED ? 2 : 8); ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x ^= acc[rg][f][r];
+        const int row = c.mt * tile_rows + c.wave * (16 * RG) + quad;
+        if (row < p.rows) out[(size_t)row * p.ld_out + c.nt * kTileCols + c16] = (uint32_t)x + pop[0];
+        return;
+    }
+#endif
+    if constexpr (!PACKED) {
+        // wave-uniform: are this wave's rows and the tile's columns all inside, away from the gadget's non-zeros?
+        const int first_row = c.mt * tile_rows + c.wave * (16 * RG), first_col = c.nt * kTileCols;
+        bool lean = first_row + 16 * RG <= p.rows && first_col + kTileCols <= p.out_cols;
+        if (lean && p.mode != kModeMul) {
+            const int j_lo = first_row / c.ell, j_hi = (first_row + 16 * RG - 1) / c.ell;
+            lean = j_hi < first_col || j_lo >= first_col + kTileCols;
+        }
+        if (lean) {
+            const bool negate = p.mode == kModeNand, digest = p.digests != nullptr;
+            if (negate && digest) gemm16_epilogue_interior<RING, RG, true, true>(p, c, tile_rows, acc, pop);
+            else if (negate) gemm16_epilogue_interior<RING, RG, true, false>(p, c, tile_rows, acc, pop);
+            else if (digest) gemm16_epilogue_interior<RING, RG, false, true>(p, c, tile_rows, acc, pop);
+            else gemm16_epilogue_interior<RING, RG, false, false>(p, c, tile_rows, acc, pop);
+            return;
+        }
+    }
     unsigned long long dig = 0;
     const bool want_digest = p.digests != nullptr;
 #pragma unroll
