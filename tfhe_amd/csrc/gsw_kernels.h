@@ -53,6 +53,12 @@ struct GemmArgs {
     const uint32_t *lhs_slot;
     const uint32_t *out_slot;
     const uint32_t *rhs_slot;
+    // Filled in by launch_gemm.  The accumulators of limb l start at acc_init[l] instead of 0: the right operand's
+    // limbs are signed digits, so a limb sum may be negative, and for Fp the start values (chosen so that
+    // sum_l 2^(8 l) acc_init[l] = 0 mod p) keep every sum non-negative without changing the result.  lean_combine:
+    // the sums stay below the bound of the 32-bit recombination (combine_limbs_lean).
+    uint32_t acc_init[4];
+    int lean_combine;
 };
 
 inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }
@@ -65,7 +71,8 @@ inline size_t prepared_bytes(int out_cols, int e4, bool packed_tail) {
 }
 
 // Right-operand preparation: src is rows_valid x cols_valid (leading dim ld_src); K-slot (e, bit) is
-// source row e*ell + bit.  dst gets [NT][e4][4 limbs][1024 B] signed (value - 128) byte planes.
+// source row e*ell + bit.  dst gets [NT][e4][4 limbs][1024 B] planes of signed base-256 digits (each in
+// [-128, 127], see signed_digits in gsw_kernels.hip).
 struct PrepArgs {
     const uint32_t *src;
     size_t src_stride;  // uint32 elements between batch entries

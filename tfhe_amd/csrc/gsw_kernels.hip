@@ -4,10 +4,10 @@
 // flattened left operand C1 = BitDecomp(C1c) collapses to Pc = BitDecomp(C1c) * C2c mod q:
 // an (N x N binary) x (N x (n+1)) contraction.  The binary operand is never materialised: its
 // int8 MFMA fragments are expanded in registers from the packed words of C1c.  The right operand
-// is split into four signed byte limbs (value - 128) stored in MFMA-fragment order, so each
-// 32x32x32 int8 MFMA consumes exactly one word per row (32 K-slots) of the left operand and one
-// 1 KiB fragment of one limb; accumulation is exact in int32 and the four limbs of one output
-// element live in the same lane, so recombination needs no cross-lane traffic.
+// is split into four signed base-256 digits (each in [-128, 127], the int8 MFMA is signed) stored in
+// MFMA-fragment order, so each 32x32x32 int8 MFMA consumes exactly one word per row (32 K-slots) of
+// the left operand and one 1 KiB fragment of one limb; accumulation is exact in int32 and the four
+// limbs of one output element live in the same lane, so recombination needs no cross-lane traffic.
 //
 // K-slot order.  Slot (h, i, t) of a word -- lane half h = lane >> 5, fragment dword i, byte t --
 // stands for bit 4h + i + 8t.  The order is free as long as both operands agree; this one makes
@@ -79,16 +79,27 @@ __device__ __forceinline__ uint64_t rng_u64(uint64_t seed, uint64_t stream, uint
     return mix64(mix64(seed ^ (stream * 0xD1342543DE82EF95ull)) + counter);
 }
 
+// The four signed base-256 digits d_l in [-128, 127] of a canonical ring element, as int8 bytes of one word:
+// sum_l d_l 256^l = x' with x' = x mod q.  y = x' + 0x80808080 propagates the carries, byte l of y is d_l + 128.
+// Four digits reach from -2155905152 to 2139062143; a word above that wraps to x - 2^32, which is the same
+// element of Z/2^M; an element of Fp above it (fewer than 2^23 of them, just below p) is taken as x - p instead.
+template <int RING>
+__device__ __forceinline__ uint32_t signed_digits(uint32_t x) {
+    if (RING == kRingFp && x > 0x7F7F7F7Fu) x -= kFpP;
+    return (x + 0x80808080u) ^ 0x80808080u;
+}
+
 // ------------------------------------------------------------------ right-operand preparation
 //
 // One workgroup per (K element e, column tile nt, batch entry): reads the 32 source rows
-// e*ell .. e*ell+31 x 32 columns (128 B contiguous per row), splits every word into four byte
-// limbs, biases them by -128 (the int8 MFMA is signed) and writes the 1 KiB fragments through
-// LDS so that the global stores are 16 B per lane and fully coalesced.
+// e*ell .. e*ell+31 x 32 columns (128 B contiguous per row), splits every word into its four signed
+// digits (signed_digits) and writes the 1 KiB fragments through LDS so that the global stores are
+// 16 B per lane and fully coalesced.  K slots past the operand keep the digit 0.
 // Full tile: thread (cc = tid & 31, i = (tid >> 5) & 3, h = tid >> 7) owns dword i of lane
 // 32h + cc in each of the four limb fragments.  Packed tail tile (at most 8 valid columns): one
 // fragment whose MFMA column l*8 + cc carries limb l of column cc.
 
+template <int RING>
 __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[4 * 256];
     const int tid = threadIdx.x;
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
             const int bit = 4 * h + i + 8 * t;
             const int row = e * ell + bit;
             if (bit < ell && row < a.rows_valid) {
-                const uint32_t x = src[(size_t)row * a.ld_src + col] ^ 0x80808080u;  // byte - 128 as int8
+                const uint32_t x = signed_digits<RING>(src[(size_t)row * a.ld_src + col]);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) limb[l] |= ((x >> (8 * l)) & 0xFFu) << (8 * t);
             }
@@ -127,6 +138,7 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
 // The same for the 16x16x64 kernels: one workgroup per (stage t, MFMA step p, column tile, batch
 // entry) builds the fragments [limb][column group] of that step from elements 4t + p (K groups 0, 1)
 // and 4t + 2 + p (K groups 2, 3).  Lane 16 g + c of a fragment: column c of the group, K group g.
+template <int RING>
 __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 256];
     const int tid = threadIdx.x;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
                 const int bit = 4 * h + i + 8 * tt;
                 const int row = e * ell + bit;
                 if (bit < ell && row < a.rows_valid) {
-                    const uint32_t x = src[(size_t)row * a.ld_src + col] ^ 0x80808080u;
+                    const uint32_t x = signed_digits<RING>(src[(size_t)row * a.ld_src + col]);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) limb[l] |= ((x >> (8 * l)) & 0xFFu) << (8 * tt);
                 }
@@ -178,10 +190,12 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
     if (a.batch <= 0) return hipSuccess;
     if (a.layout16) {
         dim3 grid((unsigned)(a.e4 / 2), (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
-        hipLaunchKernelGGL(prepare_rhs16_kernel, grid, dim3(256), 0, stream, a, ring.ell);
+        if (ring.kind == kRingFp) hipLaunchKernelGGL(prepare_rhs16_kernel<kRingFp>, grid, dim3(256), 0, stream, a, ring.ell);
+        else hipLaunchKernelGGL(prepare_rhs16_kernel<kRingZpow2>, grid, dim3(256), 0, stream, a, ring.ell);
     } else {
         dim3 grid((unsigned)a.e4, (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
-        hipLaunchKernelGGL(prepare_rhs_kernel, grid, dim3(256), 0, stream, a, ring.ell);
+        if (ring.kind == kRingFp) hipLaunchKernelGGL(prepare_rhs_kernel<kRingFp>, grid, dim3(256), 0, stream, a, ring.ell);
+        else hipLaunchKernelGGL(prepare_rhs_kernel<kRingZpow2>, grid, dim3(256), 0, stream, a, ring.ell);
     }
     return hipGetLastError();
 }
@@ -203,11 +217,11 @@ struct TileCtx {
 };
 
 // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2)
-// + 4 (lane >> 5).  The limbs were biased by -128, so every limb sum gets 128 * popcount(row)
-// back; lane r of either half holds the popcount of row r of each group.
+// + 4 (lane >> 5).  The accumulators started at GemmArgs::acc_init, so for Fp every limb sum is
+// non-negative; for Z/2^M a negative sum read as uint32 is off by a multiple of 2^32.
 template <int RING, int NFRAG>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
-                                              const v16i (&acc)[2][NFRAG], uint32_t pop0, uint32_t pop1) {
+                                              const v16i (&acc)[2][NFRAG]) {
     const int lane = c.lane, half = lane >> 5, c32 = lane & 31;
     const int col = c.nt * kTileCols + (NFRAG == 4 ? c32 : (c32 & 7));
     const bool col_owner = NFRAG == 4 ? true : c32 < 8;
@@ -217,21 +231,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
     const bool want_digest = p.digests != nullptr;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const uint32_t pop = g == 0 ? pop0 : pop1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const uint32_t bias = 128u * (uint32_t)__shfl((int)pop, rr, 64);
             const int row = c.mt * tile_rows + c.wave * 64 + g * 32 + rr;
             uint64_t s0, s1, s2, s3;
             if (NFRAG == 4) {
-                s0 = (uint32_t)acc[g][0][r] + bias;
-                s1 = (uint32_t)acc[g][1 % NFRAG][r] + bias;
-                s2 = (uint32_t)acc[g][2 % NFRAG][r] + bias;
-                s3 = (uint32_t)acc[g][3 % NFRAG][r] + bias;
+                s0 = (uint32_t)acc[g][0][r];
+                s1 = (uint32_t)acc[g][1 % NFRAG][r];
+                s2 = (uint32_t)acc[g][2 % NFRAG][r];
+                s3 = (uint32_t)acc[g][3 % NFRAG][r];
             } else {
                 // packed tile: limb l of column cc sits in MFMA column 8 l + cc of the same half
-                const int v = (int)((uint32_t)acc[g][0][r] + bias);
+                const int v = acc[g][0][r];
                 const int base = (lane & 32) | (lane & 7);
                 s0 = (uint32_t)__shfl(v, base, 64);
                 s1 = (uint32_t)__shfl(v, base + 8, 64);
@@ -279,9 +291,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &p, const TileCtx &
 // One K element: expand the two left fragments from their words and run the MFMAs.
 template <int NFRAG>
 __device__ __forceinline__ void gemm_kstep(uint32_t x0, uint32_t x1, int sh, const unsigned char *frags, int lane,
-                                           v16i (&acc)[2][NFRAG], uint32_t &pop0, uint32_t &pop1) {
-    pop0 += __popc(x0);
-    pop1 += __popc(x1);
+                                           v16i (&acc)[2][NFRAG]) {
     const uint32_t y0 = x0 >> sh, y1 = x1 >> sh;
     v4i f0, f1;
     f0[0] = (int)(y0 & 0x01010101u);
@@ -392,42 +402,60 @@ __device__ __forceinline__ void digest_commit(const GemmArgs &p, int b, int lane
     if (lane == 0) atomicAdd(&p.digests[b], dig * 0x9E3779B97F4A7C15ull);
 }
 
-// sum_l 2^(8 l) a_l as a canonical ring element, for limb sums a_l < 2^28 (at most 255 * K, K <= 2^20)
+// Start values of the accumulators (GemmArgs::acc_init): limb l of a full tile sits in accumulators 2 l and
+// 2 l + 1 of a row group; in a packed tail tile accumulator f carries limb 2 f + (column >> 3) in MFMA column
+// 8 (limb & 1) + c.
+template <int RG, int NB>
+__device__ __forceinline__ void init_acc16(v4i (&acc)[RG][NB], const GemmArgs &p, int lane) {
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            const int v = (int)(NB == 8 ? p.acc_init[f >> 1] : p.acc_init[2 * f + ((lane >> 3) & 1)]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[rg][f][r] = v;
+        }
+}
+
+// Largest limb sum the 32-bit recombination below takes: 257 a (1 + 2^-15) + 2^31 - 2^16 must stay below 2^32.
+constexpr uint32_t kLeanLimbMax = 8355000u;
+
+// sum_l 2^(8 l) a_l as a canonical ring element, for limb sums 0 <= a_l <= kLeanLimbMax (Z/2^M: any int32 read as
+// uint32).  Fp: with X = a0 + 2^8 a1 and Y = a2 + 2^8 a3 (both below 2^31), 2^16 Y = 2^31 (Y >> 15) +
+// 2^16 (Y & 0x7FFF), and 2^31 = 1 mod p, so the sum is X + (Y >> 15) + ((Y & 0x7FFF) << 16) < 2^32: one fold.
 template <int RING>
-__device__ __forceinline__ uint32_t combine_limb_sums(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t mask) {
+__device__ __forceinline__ uint32_t combine_limbs_lean(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t mask) {
     if (RING == kRingZpow2) return (a0 + (a1 << 8) + (a2 << 16) + (a3 << 24)) & mask;  // pow2_ring.rs:97-103
-    const uint64_t v = (uint64_t)a0 + ((uint64_t)a1 << 8) + ((uint64_t)a2 << 16) + ((uint64_t)a3 << 24);  // < 2^53
-    uint32_t x = ((uint32_t)v & kFpP) + (uint32_t)(v >> 31);  // 2^31 = 1 mod p; x < 2^31 + 2^22
-    x = (x & kFpP) + (x >> 31);                               // x <= p
-    return min(x, x - kFpP);                                  // p -> 0; below p the difference wraps above x
+    const uint32_t x = (a1 << 8) + a0;
+    const uint32_t y = (a3 << 8) + a2;
+    const uint32_t s = x + ((y & 0x7FFFu) << 16) + (y >> 15);
+    const uint32_t f = (s & kFpP) + (s >> 31);  // <= p
+    return min(f, f - kFpP);                    // p -> 0; below p the difference wraps above f
 }
 
 // Epilogue of a wave whose 16 RG rows x 32 columns all lie inside the product and hold no gadget entry (the one
 // non-zero of a row of G sits in column row / ell): every element is stored, nothing is tested per element,
 // nand is a plain negation and the encryption addend meets only zeros.  Same results as the general epilogue
 // below, which handles the edge tiles, the packed tail tile and the tiles that cross the gadget's diagonal band.
+// Offsets into the output are 32-bit (the caller checked rows * ld_out < 2^30).
 template <int RING, int RG, bool NEGATE, bool DIGEST>
 __device__ __forceinline__ void gemm16_epilogue_interior(const GemmArgs &p, const TileCtx &c, int tile_rows,
-                                                         const v4i (&acc)[RG][8], const uint32_t (&pop)[RG]) {
+                                                         const v4i (&acc)[RG][8]) {
     const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
-    uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
-    const int row0 = c.mt * tile_rows + c.wave * (16 * RG) + 4 * quad;
-    const int col0 = c.nt * kTileCols + c16;
+    unsigned char *out = reinterpret_cast<unsigned char *>(p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride);
+    // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
+    const uint32_t idx0 =
+        (uint32_t)(c.mt * tile_rows + c.wave * (16 * RG) + 4 * quad) * (uint32_t)p.ld_out + (uint32_t)(c.nt * kTileCols + c16);
     unsigned long long dig = 0;
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = 4 * quad + r;  // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
-            const uint32_t bias =
-                128u * (uint32_t)(__shfl((int)pop[rg], rr, 64) + __shfl((int)pop[rg], rr + 32, 64));
-            const size_t idx = (size_t)(row0 + rg * 16 + r) * p.ld_out + col0;
-            uint32_t *dst = out + idx;
+            const uint32_t idx_row = idx0 + (uint32_t)((rg * 16 + r) * p.ld_out);
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) {
-                uint32_t val = combine_limb_sums<RING>((uint32_t)acc[rg][0 + cg][r] + bias, (uint32_t)acc[rg][2 + cg][r] + bias,
-                                                       (uint32_t)acc[rg][4 + cg][r] + bias, (uint32_t)acc[rg][6 + cg][r] + bias,
-                                                       c.mask);
+                uint32_t val = combine_limbs_lean<RING>((uint32_t)acc[rg][0 + cg][r], (uint32_t)acc[rg][2 + cg][r],
+                                                        (uint32_t)acc[rg][4 + cg][r], (uint32_t)acc[rg][6 + cg][r], c.mask);
                 if (NEGATE) {
                     if (RING == kRingFp) {
                         const uint32_t t = kFpP - val;  // 0 -> p -> 0
@@ -436,10 +464,13 @@ __device__ __forceinline__ void gemm16_epilogue_interior(const GemmArgs &p, cons
                         val = (0u - val) & c.mask;
                     }
                 }
-                dst[cg * 16] = val;
+                const uint32_t idx = idx_row + 16u * cg;
+                *reinterpret_cast<uint32_t *>(out + 4u * idx) = val;
                 if (DIGEST) {
-                    const unsigned w = 2u * ((unsigned)idx + 16u * cg) + 1u;
-                    dig += (unsigned long long)val * w + w;
+                    // (x + 1) * (2 idx + 1): one 32 x 32 -> 64 multiply-add where x + 1 cannot wrap
+                    const unsigned w = 2u * idx + 1u;
+                    if (RING == kRingFp) dig += (unsigned long long)(val + 1u) * w;
+                    else dig += (unsigned long long)val * w + w;
                 }
             }
         }
@@ -449,7 +480,7 @@ __device__ __forceinline__ void gemm16_epilogue_interior(const GemmArgs &p, cons
 
 template <int RING, bool PACKED, int RG = 4>
 __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
-                                                const v4i (&acc)[RG][PACKED ? 2 : 8], const uint32_t (&pop)[RG]) {
+                                                const v4i (&acc)[RG][PACKED ? 2 : 8]) {
     const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
     uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
@@ -463,24 +494,25 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x ^= acc[rg][f][r];
         const int row = c.mt * tile_rows + c.wave * (16 * RG) + quad;
-        if (row < p.rows) out[(size_t)row * p.ld_out + c.nt * kTileCols + c16] = (uint32_t)x + pop[0];
+        if (row < p.rows) out[(size_t)row * p.ld_out + c.nt * kTileCols + c16] = (uint32_t)x;
         return;
     }
 #endif
     if constexpr (!PACKED) {
         // wave-uniform: are this wave's rows and the tile's columns all inside, away from the gadget's non-zeros?
         const int first_row = c.mt * tile_rows + c.wave * (16 * RG), first_col = c.nt * kTileCols;
-        bool lean = first_row + 16 * RG <= p.rows && first_col + kTileCols <= p.out_cols;
+        bool lean = first_row + 16 * RG <= p.rows && first_col + kTileCols <= p.out_cols &&
+                    (RING != kRingFp || p.lean_combine) && (unsigned long long)p.rows * (unsigned)p.ld_out < (1ull << 30);
         if (lean && p.mode != kModeMul) {
             const int j_lo = first_row / c.ell, j_hi = (first_row + 16 * RG - 1) / c.ell;
             lean = j_hi < first_col || j_lo >= first_col + kTileCols;
         }
         if (lean) {
             const bool negate = p.mode == kModeNand, digest = p.digests != nullptr;
-            if (negate && digest) gemm16_epilogue_interior<RING, RG, true, true>(p, c, tile_rows, acc, pop);
-            else if (negate) gemm16_epilogue_interior<RING, RG, true, false>(p, c, tile_rows, acc, pop);
-            else if (digest) gemm16_epilogue_interior<RING, RG, false, true>(p, c, tile_rows, acc, pop);
-            else gemm16_epilogue_interior<RING, RG, false, false>(p, c, tile_rows, acc, pop);
+            if (negate && digest) gemm16_epilogue_interior<RING, RG, true, true>(p, c, tile_rows, acc);
+            else if (negate) gemm16_epilogue_interior<RING, RG, true, false>(p, c, tile_rows, acc);
+            else if (digest) gemm16_epilogue_interior<RING, RG, false, true>(p, c, tile_rows, acc);
+            else gemm16_epilogue_interior<RING, RG, false, false>(p, c, tile_rows, acc);
             return;
         }
     }
@@ -492,9 +524,6 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
         for (int r = 0; r < 4; ++r) {
             // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
             const int rr = 4 * quad + r;
-            // the words of row rr were split between the K groups: lanes rr (elements p) and rr + 32 (p + 2)
-            const uint32_t bias =
-                128u * (uint32_t)(__shfl((int)pop[rg], rr, 64) + __shfl((int)pop[rg], rr + 32, 64));
             const int row = c.mt * tile_rows + c.wave * (16 * RG) + rg * 16 + rr;
 #pragma unroll
             for (int cg = 0; cg < (PACKED ? 1 : 2); ++cg) {
@@ -502,14 +531,14 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                 int col;
                 bool owner;
                 if (!PACKED) {
-                    s0 = (uint32_t)acc[rg][(0 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
-                    s1 = (uint32_t)acc[rg][(1 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
-                    s2 = (uint32_t)acc[rg][(2 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
-                    s3 = (uint32_t)acc[rg][(3 * 2 + cg) % (PACKED ? 2 : 8)][r] + bias;
+                    s0 = (uint32_t)acc[rg][(0 * 2 + cg) % (PACKED ? 2 : 8)][r];
+                    s1 = (uint32_t)acc[rg][(1 * 2 + cg) % (PACKED ? 2 : 8)][r];
+                    s2 = (uint32_t)acc[rg][(2 * 2 + cg) % (PACKED ? 2 : 8)][r];
+                    s3 = (uint32_t)acc[rg][(3 * 2 + cg) % (PACKED ? 2 : 8)][r];
                     col = c.nt * kTileCols + cg * 16 + c16;
                     owner = true;
                 } else {
-                    const int v0 = (int)((uint32_t)acc[rg][0][r] + bias), v1 = (int)((uint32_t)acc[rg][1][r] + bias);
+                    const int v0 = acc[rg][0][r], v1 = acc[rg][1][r];
                     const int base = (lane & 48) | (lane & 7);
                     s0 = (uint32_t)__shfl(v0, base, 64);
                     s1 = (uint32_t)__shfl(v0, base + 8, 64);
@@ -624,13 +653,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     }
 
     v4i acc[4][kNB];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    init_acc16(acc, p, lane);
     const int r16 = lane & 15;
     const int sh = ((lane >> 4) & 1) * 4;
     const int swz = (r16 >> 2) & 3;
@@ -685,7 +708,6 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 w[rg] = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
-                pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
             }
             constexpr int kGroup = PACKED ? 2 : 4;
             constexpr int kGroups = 2 * kNB / kGroup;
@@ -751,7 +773,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave_active) {
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc, pop);
+        gemm16_epilogue<RING, PACKED>(p, c, kRows, acc);
     }
 }
 
@@ -800,15 +822,7 @@ __device__ __forceinline__ void gemm16_tall_body(const GemmArgs &p, int ell, uin
     }
 
     v4i acc[RG][kNB];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) pop[rg] = 0u;
+    init_acc16(acc, p, lane);
     const int r16 = lane & 15;
     const int sh = ((lane >> 4) & 1) * 4;
     const int swz = (r16 >> 2) & 3;
@@ -863,7 +877,6 @@ __device__ __forceinline__ void gemm16_tall_body(const GemmArgs &p, int ell, uin
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 w[rg] = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
-                pop[rg] += __popc(w[rg].x) + __popc(w[rg].y);
             }
             constexpr int kGroup = PACKED ? 2 : 4;
             constexpr int kGroups = 2 * kNB / kGroup;
@@ -929,7 +942,7 @@ __device__ __forceinline__ void gemm16_tall_body(const GemmArgs &p, int ell, uin
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave_active) {
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, PACKED, RG>(p, c, kRows, acc, pop);
+        gemm16_epilogue<RING, PACKED, RG>(p, c, kRows, acc);
     }
 }
 
@@ -968,15 +981,7 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
     }
 
     v4i acc[RG][kNB];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) pop[rg] = 0u;
+    init_acc16(acc, p, lane);
     const int r16 = lane & 15;
     const int sh = ((lane >> 4) & 1) * 4;
     const int swz = (r16 >> 2) & 3;
@@ -1014,10 +1019,6 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
             wx[rg] = w.x;
             wy[rg] = w.y;
         }
-    };
-    auto count_words = [&](const uint32_t (&wx)[RG], const uint32_t (&wy)[RG]) {
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) pop[rg] += __popc(wx[rg]) + __popc(wy[rg]);
     };
     // keeps the compiler from sinking a fragment set's expansion below this point
     auto pin = [&](v4i (&fa)[RG]) {
@@ -1071,9 +1072,9 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
     for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, 1, j);
 
     v4i fa0[RG], fa1[RG], fbA[4], fbB[4];
-    uint32_t wx[RG], wy[RG];
+    uint32_t wy[RG];  // the second words (MFMA step 1) of the current stage
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) wx[rg] = wy[rg] = 0u;  // the current stage's words (wx: for counting)
+    for (int rg = 0; rg < RG; ++rg) wy[rg] = 0u;
     int buf = 0;
 
     auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t) {
@@ -1087,19 +1088,16 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
             for (int q = 0; q < 4; ++q) issue_portion(t, buf, opens, q);
         } else {
             if constexpr (kFirst) {
+                uint32_t wx[RG];
                 read_words(t, wx, wy);
-                count_words(wx, wy);
                 expand(fa0, wx);
             }
-            // phase 0: first fragments of this stage; the previous stage's last group covers their
-            // latency, and this stage's words are counted between its MFMAs
+            // phase 0: first fragments of this stage; the previous stage's last group covers their latency
             read_frags(fbA, buf, 0);
             issue_portion(t, buf, opens, 0);
             if constexpr (!kFirst) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(fa1, fbB, 4);
-                count_words(wx, wy);
-                interleave(std::integral_constant<int, 1>{});
             }
             __builtin_amdgcn_sched_barrier(0);
             // phase 1: step 0, fragments 0..3; the step-1 fragments of this stage are expanded meanwhile
@@ -1124,10 +1122,7 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
             expand(fa0, nx);
             pin(fa0);
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                wx[rg] = nx[rg];
-                wy[rg] = ny[rg];
-            }
+            for (int rg = 0; rg < RG; ++rg) wy[rg] = ny[rg];
             interleave(std::integral_constant<int, 2>{});
             __builtin_amdgcn_sched_barrier(0);
             // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
@@ -1152,7 +1147,7 @@ __device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell
     if (wave_active) {
         mfma_group(fa1, fbB, 4);  // the last stage's deferred group
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, false, RG>(p, c, kRows, acc, pop);
+        gemm16_epilogue<RING, false, RG>(p, c, kRows, acc);
     }
 }
 
@@ -1225,13 +1220,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     }
 
     v4i acc[4][kNB];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-        for (int f = 0; f < kNB; ++f)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[rg][f][r] = 0;
-    uint32_t pop[4] = {0u, 0u, 0u, 0u};
+    init_acc16(acc, p, lane);
     const int r16 = lane & 15;
     const int sh = ((lane >> 4) & 1) * 4;
     const int swz = (r16 >> 2) & 3;
@@ -1266,10 +1255,6 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             wx[rg] = w.x;
             wy[rg] = w.y;
         }
-    };
-    auto count_words = [&](const uint32_t (&wx)[4], const uint32_t (&wy)[4]) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) pop[rg] += __popc(wx[rg]) + __popc(wy[rg]);
     };
     // keeps the compiler from sinking a fragment set's expansion below this point
     auto pin = [&](v4i (&fa)[4]) {
@@ -1322,7 +1307,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, 1, j);
 
     v4i fa0[4], fa1[4], fbA[4], fbB[4];
-    uint32_t wx[4] = {0u, 0u, 0u, 0u}, wy[4] = {0u, 0u, 0u, 0u};  // the current stage's words (wx: for counting)
+    uint32_t wy[4] = {0u, 0u, 0u, 0u};  // the second words (MFMA step 1) of the current stage
     int buf = 0;
 
     auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t) {
@@ -1336,19 +1321,16 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             for (int q = 0; q < 4; ++q) issue_portion(t, buf, opens, q);
         } else {
             if constexpr (kFirst) {
+                uint32_t wx[4];
                 read_words(t, wx, wy);
-                count_words(wx, wy);
                 expand(fa0, wx);
             }
-            // phase 0: first fragments of this stage; the previous stage's last group covers their
-            // latency, and this stage's words are counted between its MFMAs
+            // phase 0: first fragments of this stage; the previous stage's last group covers their latency
             read_frags(fbA, buf, 0);
             issue_portion(t, buf, opens, 0);
             if constexpr (!kFirst) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(fa1, fbB, 4);
-                count_words(wx, wy);
-                interleave(std::integral_constant<int, 1>{});
             }
             __builtin_amdgcn_sched_barrier(0);
             // phase 1: step 0, fragments 0..3; the step-1 fragments of this stage are expanded meanwhile
@@ -1373,10 +1355,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             expand(fa0, nx);
             pin(fa0);
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                wx[rg] = nx[rg];
-                wy[rg] = ny[rg];
-            }
+            for (int rg = 0; rg < 4; ++rg) wy[rg] = ny[rg];
             interleave(std::integral_constant<int, 2>{});
             __builtin_amdgcn_sched_barrier(0);
             // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
@@ -1401,7 +1380,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     if (wave_active) {
         mfma_group(fa1, fbB, 4);  // the last stage's deferred group
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, false>(p, c, kRows, acc, pop);
+        gemm16_epilogue<RING, false>(p, c, kRows, acc);
     }
 }
 
@@ -1500,8 +1479,7 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
 #pragma unroll
         for (int l = 0; l < 4; ++l)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][l][r] = 0;
-    uint32_t pop0 = 0, pop1 = 0;
+            for (int r = 0; r < 16; ++r) acc[g][l][r] = (int)p.acc_init[l];
     const int r32 = lane & 31;
     const int sh = (lane >> 5) * 4;
 
@@ -1523,18 +1501,63 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
         const unsigned char *sb = sa + kStageLhsBytes;
         const uint4 a0 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + r32) * 16);
         const uint4 a1 = *reinterpret_cast<const uint4 *>(sa + (wave * 64 + 32 + r32) * 16);
-        gemm_kstep<4>(a0.x, a1.x, sh, sb + 0 * 4 * kFragBytes, lane, acc, pop0, pop1);
-        gemm_kstep<4>(a0.y, a1.y, sh, sb + 1 * 4 * kFragBytes, lane, acc, pop0, pop1);
-        gemm_kstep<4>(a0.z, a1.z, sh, sb + 2 * 4 * kFragBytes, lane, acc, pop0, pop1);
-        gemm_kstep<4>(a0.w, a1.w, sh, sb + 3 * 4 * kFragBytes, lane, acc, pop0, pop1);
+        gemm_kstep<4>(a0.x, a1.x, sh, sb + 0 * 4 * kFragBytes, lane, acc);
+        gemm_kstep<4>(a0.y, a1.y, sh, sb + 1 * 4 * kFragBytes, lane, acc);
+        gemm_kstep<4>(a0.z, a1.z, sh, sb + 2 * 4 * kFragBytes, lane, acc);
+        gemm_kstep<4>(a0.w, a1.w, sh, sb + 3 * 4 * kFragBytes, lane, acc);
         __syncthreads();
     }
     const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-    gemm_epilogue<RING, 4>(p, c, kTileRows, acc, pop0, pop1);
+    gemm_epilogue<RING, 4>(p, c, kTileRows, acc);
 }
 
-hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream) {
-    if (a.batch <= 0) return hipSuccess;
+// Start values C_l of the four limb accumulators for Fp (Z/2^M starts at 0: a negative sum read as uint32 is off
+// by a multiple of 2^32).  A limb sum lies in [-128 k, 127 k] for k K-slots, so C_l >= 128 k keeps it
+// non-negative, and sum_l 2^(8 l) C_l = 0 mod p leaves the recombined value unchanged.  With all C_l + 127 k
+// below `top` (kLeanLimbMax for the 32-bit recombination, else 2^28 for the 64-bit one).  C_3 and C_2 are
+// stepped until the target -(2^16 C_2 + 2^24 C_3) mod p has a representative C_0 + 2^8 C_1 in range, which
+// covers every integer of [257 lo, 257 hi] once hi - lo >= 255.
+static bool fp_acc_init(long k_slots, long top, uint32_t (&c)[4]) {
+    const long lo = 128 * k_slots, hi = top - 127 * k_slots;
+    if (hi - lo < 255) return false;
+    const long P = (long)kFpP;
+    const long span = hi - lo < 2048 ? hi - lo : 2048;
+    for (long c3 = lo; c3 <= lo + span; ++c3) {
+        for (long c2 = lo; c2 <= lo + span; ++c2) {
+            const long t = (P - (long)((((unsigned __int128)c2 << 16) + ((unsigned __int128)c3 << 24)) % (unsigned long)P)) % P;
+            long v = t;
+            if (v < 257 * lo) v += (257 * lo - v + P - 1) / P * P;
+            if (v > 257 * hi) continue;
+            long c1 = (v - lo) / 256;
+            if (c1 > hi) c1 = hi;
+            const long c0 = v - 256 * c1;
+            if (c0 < lo || c0 > hi || c1 < lo) continue;
+            c[0] = (uint32_t)c0, c[1] = (uint32_t)c1, c[2] = (uint32_t)c2, c[3] = (uint32_t)c3;
+            return true;
+        }
+    }
+    return false;
+}
+
+hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, hipStream_t stream) {
+    if (args.batch <= 0) return hipSuccess;
+    GemmArgs a = args;
+    a.acc_init[0] = a.acc_init[1] = a.acc_init[2] = a.acc_init[3] = 0u;
+    a.lean_combine = 1;
+    if (ring.kind == kRingFp) {
+        // every left-operand word carries at most 32 ones; K slots past the right operand meet the digit 0
+        thread_local long cached_slots = -1;
+        thread_local uint32_t cached_init[4];
+        thread_local int cached_lean;
+        const long k_slots = 32L * a.e4;
+        if (k_slots != cached_slots) {
+            cached_lean = fp_acc_init(k_slots, (long)kLeanLimbMax, cached_init) ? 1 : 0;
+            if (!cached_lean && !fp_acc_init(k_slots, 1L << 28, cached_init)) return hipErrorInvalidValue;
+            cached_slots = k_slots;
+        }
+        for (int l = 0; l < 4; ++l) a.acc_init[l] = cached_init[l];
+        a.lean_combine = cached_lean;
+    }
 #ifdef GSW_DIAGNOSTIC_BUILDS
     if (variant >= 10 && variant < 138 && ring.kind == kRingFp) {
         // diagnostic builds: variant = 10 + ABL
