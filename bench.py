@@ -50,6 +50,10 @@ WORKLOADS = {
     "fp_n512": (lambda: tfhe_amd.Fp(), 512, 256),       # the 8-GPU configuration's shape (n = 512), a short batch
     "z32_n512": (lambda: tfhe_amd.Zpow2(32), 512, 256),  # the power-of-two ring configuration's shape (q = 2^32, n = 512)
     "fp_n10": (lambda: tfhe_amd.Fp(), 10, 1024),        # the reference's own test parameters (plumbing)
+    # diagnostic shapes without any padding (n + 1 a multiple of 32, rows a multiple of 128): tile time vs K depth
+    "fp_n127": (lambda: tfhe_amd.Fp(), 127, 4096),
+    "fp_n255": (lambda: tfhe_amd.Fp(), 255, 1024),
+    "fp_n511": (lambda: tfhe_amd.Fp(), 511, 256),
 }
 # --config K: configuration K (1-based) of the benchmark list at its real per-GPU size -> (workload, batch per GPU, pool)
 CONFIGS = {

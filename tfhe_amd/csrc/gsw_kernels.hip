@@ -14,6 +14,7 @@
 // the left fragment two VALU ops per dword: ((x >> 4h) >> i) & 0x01010101.
 #include "gsw_kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace gswk {
@@ -1542,6 +1543,16 @@ static bool fp_acc_init(long k_slots, long top, uint32_t (&c)[4]) {
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, hipStream_t stream) {
     if (args.batch <= 0) return hipSuccess;
     GemmArgs a = args;
+#ifdef GSW_DIAGNOSTIC_BUILDS
+    // timing-only ablations of the shape's padding (wrong or partial results): what the tail column tile, the
+    // thin last row tile and the last, mostly empty K stage cost
+    if (const char *e = getenv("GSW_ABL_SHAPE")) {
+        const int m = atoi(e);
+        if ((m & 1) && a.out_cols % kTileCols) a.out_cols -= a.out_cols % kTileCols, a.packed_tail = 0;
+        if ((m & 2) && a.rows % kTileRows) a.rows -= a.rows % kTileRows;
+        if ((m & 4) && a.e4 > kStageElems) a.e4 -= kStageElems;  // the prepared operand keeps its stride: wrong data, same work per stage
+    }
+#endif
     a.acc_init[0] = a.acc_init[1] = a.acc_init[2] = a.acc_init[3] = 0u;
     a.lean_combine = 1;
     if (ring.kind == kRingFp) {
