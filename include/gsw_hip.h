@@ -307,6 +307,14 @@ int gsw_wire_read_compact(gsw_ctx *ctx, const void *h_in, size_t in_bytes, uint3
  * on a known byte count in those patterns.  src_bytes is the size of the buffer behind d_src. */
 int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size_t bytes, int mode, size_t pitch);
 
+/* Test aid, no counterpart in the reference, host only (no context, no GPU).  The right operand of the
+ * contraction is held as four signed base-256 digits per element, so a limb sum over k_slots K slots lies in
+ * [-128 k_slots, 127 k_slots]; the accumulators of limb l start at h_start4[l] instead of 0.  For Fp these keep
+ * every sum non-negative and satisfy sum_l 2^(8 l) h_start4[l] = 0 mod p, so the recombined value is unchanged;
+ * for Z/2^M they vanish mod 2^32.  *lean_out: the sums stay small enough for the 32-bit recombination
+ * (`wide` != 0 asks for the values of the 64-bit one).  `bits` is M for GSW_RING_ZPOW2 and ignored for Fp. */
+int gsw_diag_limb_start_values(int ring_kind, int bits, int k_slots, int wide, uint32_t *h_start4, int *lean_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -749,3 +749,64 @@ def test_depth8_chain_n256(oracle, tfhe_amd):
                   f"q/4 = {ring_o.q // 4}")
             assert noise < 1.5 * i * per_level + 1000 < ring_o.q // 4
             prev = cur
+
+
+# ---------------------------------------------------------------- signed digits and accumulator start values
+_EDGE_FP = [0, 1, 127, 128, 255, 256, 0x7F7F7F7F, 0x7F7F7F80, 0x7F7F7F81, 0x7F800000, 0x7FFFFF7F, 0x7FFFFF80, P - 2, P - 1]
+_EDGE_Z32 = _EDGE_FP + [0x80000000, 0x80808080, 0x7FFFFFFF, 0xFFFFFF7F, 0xFFFFFF80, 0xFFFFFFFF]
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("ring_name,n", [("fp", 10), ("fp", 40), ("fp", 71), ("z32", 10), ("z32", 40), ("z31", 33)])
+def test_mul_gadget_edge_valued_right_operands(oracle, tfhe_amd, ring_name, n, wide):
+    """Right operands made of the values where the signed-digit split changes branch (carries into the top digit,
+    the elements of Fp taken as x - p, the words of Z/2^32 that wrap), against left operands of all ones, all
+    zeros and random words, so that the limb sums reach both ends of their range; with the 32-bit recombination
+    and, forced, with the 64-bit one."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=1)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    rng = np.random.default_rng(300 + n)
+    edges = np.array([v for v in (_EDGE_FP if ring_name == "fp" else _EDGE_Z32) if v < ring_o.q], dtype=np.uint32)
+    c1, c2 = _rand_compact(rng, ring_o, n, 4), _rand_compact(rng, ring_o, n, 4)
+    c2[0] = edges[rng.integers(0, len(edges), size=c2[0].shape)]
+    c2[1] = edges[rng.integers(len(edges) - 4, len(edges), size=c2[1].shape)]  # the largest values only
+    c2[2] = ring_o.q - 1
+    c1[1] = ring_o.q - 1 if ring_name != "fp" else 0x7FFFFFFE  # p - 1: every bit but the lowest
+    c1[2] = 0
+    c1[3, ::2] = ring_o.q - 1
+    if wide:
+        os.environ["GSW_FORCE_WIDE_COMBINE"] = "1"
+    try:
+        d1 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c1)
+        d2 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)
+        got = gsw.mult(d1, d2).to_compact()
+        got_nand = gsw.nand(d1, d2).to_compact()
+    finally:
+        os.environ.pop("GSW_FORCE_WIDE_COMBINE", None)
+    for b in range(4):
+        _assert_equal(got[b], og.mul_gadget(c1[b], c2[b]), f"mult[{b}] {ring_name} n={n} wide={wide}")
+        _assert_equal(got_nand[b], og.mul_gadget(c1[b], c2[b], flags=oracle.FLAG_NAND), f"nand[{b}] {ring_name} n={n}")
+
+
+def test_n256_rows_with_the_64_bit_recombination(oracle, tfhe_amd):
+    """The fallback for contractions too long for the 32-bit recombination (more than about 32 000 K slots), forced
+    at n = 256 where interior tiles exist: sampled rows of one product against the oracle."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 256
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
+    og = oracle.GSW(ring_o, n, n * 31)
+    rng = np.random.default_rng(77)
+    c1, c2 = _rand_compact(rng, ring_o, n), _rand_compact(rng, ring_o, n)
+    os.environ["GSW_FORCE_WIDE_COMBINE"] = "1"
+    try:
+        wide = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1),
+                        tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    finally:
+        os.environ.pop("GSW_FORCE_WIDE_COMBINE", None)
+    lean = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1),
+                    tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    _assert_equal(wide, lean, "64-bit vs 32-bit recombination, whole product")
+    rows = np.concatenate([np.arange(0, 4), rng.integers(0, ring_o.big_n(n), 24), np.arange(ring_o.big_n(n) - 4, ring_o.big_n(n))])
+    for r in rows:
+        _assert_equal(wide[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")

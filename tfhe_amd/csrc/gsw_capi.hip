@@ -1669,6 +1669,20 @@ int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size
     return GSW_OK;
 }
 
+int gsw_diag_limb_start_values(int ring_kind, int bits, int k_slots, int wide, uint32_t *h_start4, int *lean_out) {
+    if (!h_start4 || !lean_out || k_slots <= 0 || (ring_kind != GSW_RING_FP_M31 && ring_kind != GSW_RING_ZPOW2))
+        return fail(GSW_E_INVALID, "bad argument");
+    gswk::RingDesc ring;
+    ring.kind = ring_kind == GSW_RING_FP_M31 ? gswk::kRingFp : gswk::kRingZpow2;
+    ring.ell = ring_kind == GSW_RING_FP_M31 ? 31 : bits;
+    ring.mask = ring_kind == GSW_RING_FP_M31 ? gswk::kFpP : (bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u);
+    uint32_t c[4];
+    if (!gswk::limb_start_values(ring, k_slots, wide != 0, c, lean_out))
+        return fail(GSW_E_INVALID, "no start values for %d K slots", k_slots);
+    for (int l = 0; l < 4; ++l) h_start4[l] = c[l];
+    return GSW_OK;
+}
+
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch, uint64_t *d_digests) {
     if (!ctx || !d_x || !d_digests || batch < 0) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;

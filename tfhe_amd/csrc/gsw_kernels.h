@@ -97,6 +97,9 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
 //          6 = 16x16x64 with 64-byte left-operand loads, 256-row tile; 7 = same, 512-row tile.
 // The prepared right operand must have been built for the variant's fragment order.
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
+// The accumulator start values launch_gemm uses for a contraction over k_slots K slots (GemmArgs::acc_init) and
+// whether the 32-bit recombination applies (host only; `wide` asks for the 64-bit one).  False: no values exist.
+bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (&c)[4], int *lean);
 
 // output formats of the gadget decomposition (GSW_DECOMP_* of the C header)
 constexpr int kDecompU32 = 0;   // one uint32 per bit: the reference's matrix of ring 0 / 1 values

@@ -1540,9 +1540,39 @@ static bool fp_acc_init(long k_slots, long top, uint32_t (&c)[4]) {
     return false;
 }
 
+bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (&c)[4], int *lean) {
+    *lean = 1;
+    if (ring.kind != kRingFp) {
+        // Z/2^M needs no start values (a sum read as uint32 is right mod 2^32 whatever its sign), but sums that
+        // hover around 0 change sign all the time and every change flips the upper bits of the accumulator: start
+        // values that vanish mod 2^32 (2^24 + 2^8 (2^24 - 2^16) = 2^32) keep them positive, 1.5 % faster at n = 512
+        c[0] = 1u << 24, c[1] = (1u << 24) - (1u << 16), c[2] = 1u << 24, c[3] = 1u << 24;
+        return true;
+    }
+    if (!wide && fp_acc_init(k_slots, (long)kLeanLimbMax, c)) return true;
+    *lean = 0;
+    return fp_acc_init(k_slots, 1L << 28, c);
+}
+
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, hipStream_t stream) {
     if (args.batch <= 0) return hipSuccess;
     GemmArgs a = args;
+    {
+        // every left-operand word carries at most 32 ones; K slots past the right operand meet the digit 0.
+        // GSW_FORCE_WIDE_COMBINE=1 (tests): the 64-bit recombination and its start values at any size.
+        thread_local long cached_slots = -1;
+        thread_local int cached_kind = -1, cached_wide = -1, cached_lean = 0;
+        thread_local uint32_t cached_init[4];
+        const long k_slots = 32L * a.e4;
+        const char *env = getenv("GSW_FORCE_WIDE_COMBINE");
+        const int wide = env && env[0] == '1';
+        if (k_slots != cached_slots || ring.kind != cached_kind || wide != cached_wide) {
+            if (!limb_start_values(ring, k_slots, wide, cached_init, &cached_lean)) return hipErrorInvalidValue;
+            cached_slots = k_slots, cached_kind = ring.kind, cached_wide = wide;
+        }
+        for (int l = 0; l < 4; ++l) a.acc_init[l] = cached_init[l];
+        a.lean_combine = cached_lean;
+    }
 #ifdef GSW_DIAGNOSTIC_BUILDS
     // timing-only ablations of the shape's padding (wrong or partial results): what the tail column tile, the
     // thin last row tile and the last, mostly empty K stage cost
