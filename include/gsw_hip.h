@@ -138,9 +138,11 @@ int gsw_ctx_last_dense_path(const gsw_ctx *ctx);
  *      an operand (GSW_E_INVALID): the reference returns a fresh matrix (gsw_impl.rs:107). ---- */
 /* Invariants of the operands, relied upon but not tested by the contraction (gsw_validate_compact tests
  * them): every word is a canonical ring value (no bit at or above ell), and every padding word of a row
- * (columns n + 1 .. ld - 1) is zero.  A stray bit in the left operand would be counted by the signed-limb
- * correction without a matching limb and shift every limb of that row by a multiple of 128.  Everything
- * this library writes keeps the invariant; a caller that fills a buffer itself must zero the padding. */
+ * (columns n + 1 .. ld - 1) is zero.  The right operand is split into signed base-256 digits on the
+ * assumption that its words are canonical (an element of Fp at or above p comes out as another element).  In
+ * the left operand a bit at or above ell, or a padding word, only meets K slots whose digits are 0.
+ * Everything this library writes keeps the invariant (products write zeros into the padding of their
+ * output); a caller that fills a buffer itself should zero the padding. */
 /* *h_bad_out = number of words, over `batch` compact ciphertexts, that are not canonical or are non-zero
  * padding.  Waits for the stream. */
 int gsw_validate_compact(gsw_ctx *ctx, const uint32_t *d_cc, size_t stride, int batch, uint64_t *h_bad_out);

@@ -777,6 +777,7 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
             a.out_stride = (size_t)dim;
             a.rows = dim < slab ? dim : slab;
             a.e4 = ctx->e4;
+    a.k_words = ctx->width;
             a.ld_lhs = ctx->ld;
             a.out_cols = dim;
             a.ld_out = dim;
@@ -880,6 +881,7 @@ static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, con
     a.addend = nullptr;
     a.rows = ctx->big_n;
     a.e4 = ctx->e4;
+    a.k_words = ctx->width;
     a.ld_lhs = ctx->ld;
     a.out_cols = ctx->width;
     a.ld_out = ctx->ld;
@@ -1360,6 +1362,7 @@ int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d
     a.addend = d_messages;
     a.rows = ctx->big_n;
     a.e4 = ctx->ld_r;
+    a.k_words = ctx->words;
     a.ld_lhs = ctx->ld_r;
     a.out_cols = ctx->width;
     a.ld_out = ctx->ld;

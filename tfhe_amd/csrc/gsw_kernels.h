@@ -39,6 +39,8 @@ struct GemmArgs {
     const uint32_t *addend;  // kModeEncrypt: one message per batch entry
     int rows;                // M
     int e4;                  // left-operand words per row, multiple of kStageElems
+    int k_words;             // of which the first k_words meet right-operand digits that may be non-zero (0: not stated,
+                             // all of them); lets the kernel drop the MFMA step of a last stage that holds padding only
     int ld_lhs;
     int out_cols;  // valid output columns W
     int ld_out;

@@ -1311,10 +1311,14 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     uint32_t wy[4] = {0u, 0u, 0u, 0u};  // the second words (MFMA step 1) of the current stage
     int buf = 0;
 
-    auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t) {
+    // kHalf: the last stage of a K dimension whose last real word is the stage's first (n + 1 = 1 mod 4, as for
+    // every n that is a multiple of 4): MFMA step 1 pairs the stage's words 1 and 3, which meet only zero digits,
+    // so its two groups, their fragment reads and the expansion of its left fragments are left out.
+    auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t, auto half_tag) {
         constexpr int kSlot = decltype(slot_tag)::value;
         constexpr bool kFirst = decltype(first_tag)::value;
         constexpr bool kActive = decltype(active_tag)::value;
+        constexpr bool kHalf = decltype(half_tag)::value;
         wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
         const bool opens = kSlot == 0;
         if constexpr (!kActive) {
@@ -1338,48 +1342,61 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             read_frags(fbB, buf, 1);
             issue_portion(t, buf, opens, 1);
             mfma_group(fa0, fbA, 0);
-            expand(fa1, wy);
-            pin(fa1);
-            interleave(std::integral_constant<int, 2>{});
+            if constexpr (!kHalf) {
+                expand(fa1, wy);
+                pin(fa1);
+                interleave(std::integral_constant<int, 2>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: step 0, fragments 4..7; the next stage's left-operand words are fetched
-            read_frags(fbA, buf, 2);
+            if constexpr (!kHalf) read_frags(fbA, buf, 2);
             issue_portion(t, buf, opens, 2);
             mfma_group(fa0, fbB, 4);
-            uint32_t nx[4], ny[4];
-            read_words(t + 1, nx, ny);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 3: step 1, fragments 0..3; the next stage's step-0 fragments are expanded
-            read_frags(fbB, buf, 3);
-            issue_portion(t, buf, opens, 3);
-            mfma_group(fa1, fbA, 0);
-            expand(fa0, nx);
-            pin(fa0);
+            if constexpr (kHalf) {
+                issue_portion(t, buf, opens, 3);  // the counted waits of the loads stay as they are
+            } else {
+                uint32_t nx[4], ny[4];
+                read_words(t + 1, nx, ny);
+                __builtin_amdgcn_sched_barrier(0);
+                // phase 3: step 1, fragments 0..3; the next stage's step-0 fragments are expanded
+                read_frags(fbB, buf, 3);
+                issue_portion(t, buf, opens, 3);
+                mfma_group(fa1, fbA, 0);
+                expand(fa0, nx);
+                pin(fa0);
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) wy[rg] = ny[rg];
-            interleave(std::integral_constant<int, 2>{});
+                for (int rg = 0; rg < 4; ++rg) wy[rg] = ny[rg];
+                interleave(std::integral_constant<int, 2>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
             // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
         }
         buf = buf == 2 ? 0 : buf + 1;
     };
+    // the last stage may be a half one; it is the only stage of a loop turn when stages = 1 mod 4 (slot 0)
+    const bool half_last = p.k_words > 0 && p.k_words + 3 == p.e4 && stages > 4 && (stages & 3) == 1;
+    const int full_stages = half_last ? stages - 1 : stages;
     auto main_loop = [&](auto active_tag) {
-        stage(std::integral_constant<int, 0>{}, std::true_type{}, active_tag, 0);
-        if (1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, 1);
-        if (2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, 2);
-        if (3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, 3);
-        for (int t0 = 4; t0 < stages; t0 += 4) {
-            stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, t0);
-            if (t0 + 1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, t0 + 1);
-            if (t0 + 2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, t0 + 2);
-            if (t0 + 3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, t0 + 3);
+        stage(std::integral_constant<int, 0>{}, std::true_type{}, active_tag, 0, std::false_type{});
+        if (1 < full_stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, 1, std::false_type{});
+        if (2 < full_stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, 2, std::false_type{});
+        if (3 < full_stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, 3, std::false_type{});
+        for (int t0 = 4; t0 < full_stages; t0 += 4) {
+            stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, t0, std::false_type{});
+            if (t0 + 1 < full_stages)
+                stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, t0 + 1, std::false_type{});
+            if (t0 + 2 < full_stages)
+                stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, t0 + 2, std::false_type{});
+            if (t0 + 3 < full_stages)
+                stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, t0 + 3, std::false_type{});
         }
+        if (half_last) stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, stages - 1, std::true_type{});
     };
     if (wave_active) main_loop(std::true_type{});
     else main_loop(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave_active) {
-        mfma_group(fa1, fbB, 4);  // the last stage's deferred group
+        if (!half_last) mfma_group(fa1, fbB, 4);  // the last stage's deferred group
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
         gemm16_epilogue<RING, false>(p, c, kRows, acc);
     }
