@@ -9,7 +9,8 @@ SOURCES = [os.path.join(HERE, "csrc", "gsw_kernels.hip"), os.path.join(HERE, "cs
            os.path.join(HERE, "csrc", "gsw_wire.cpp")]  # gsw_wire.cpp: host-only (wire format parser, sampler table)
 HEADERS = [os.path.join(HERE, "csrc", "gsw_kernels.h"), os.path.join(HERE, "csrc", "gsw_wire.h"),
            os.path.join(HERE, "..", "include", "gsw_hip.h")]
-# -DGSW_DIAGNOSTIC_BUILDS additionally compiles csrc/gsw_kernels_diag.inc (superseded kernels, for A/B timing)
+# -DGSW_DIAGNOSTIC_BUILDS additionally compiles csrc/gsw_kernels_diag.inc (superseded kernels, for A/B timing),
+# -DGSW_EXP_TALL csrc/gsw_kernels_tall.inc (the tall-tile experiment)
 OUT = os.path.join(HERE, "libgsw_hip.so")
 
 

@@ -778,402 +778,11 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     }
 }
 
+// The tall-tile experiment (variants 10 / 11): only in libraries built with -DGSW_EXP_TALL.
 #ifdef GSW_EXP_TALL
-#ifndef GSW_SKEW_INTERLEAVE
-#define GSW_SKEW_INTERLEAVE 1
+#include "gsw_kernels_tall.inc"
 #endif
-// ---- Tall tile (experiment): 4 waves, one workgroup per CU, a wave owns RG row groups (128 rows at RG = 8) of the
-// 32-column tile with its accumulators spread over the 512 registers a lone wave per SIMD may use.  Every
-// right-operand fragment read from LDS then feeds 8 MFMAs instead of 4, and a stage moves half the right-operand
-// bytes per MFMA from L2.  Same rings and counted waits as the row-block body.
-template <int RG>
-constexpr int tall_lds_bytes() { return 2 * 4 * RG * 1024 + kPipeBuffers * kStageElems * 4 * kFragBytes; }
 
-template <int RING, int RG, bool PACKED>
-__device__ __forceinline__ void gemm16_tall_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
-                                                     int mt, unsigned char *smem) {
-    constexpr int WAVES = 4;
-    constexpr int kWaveRows = 16 * RG;                  // rows of a wave: RG row groups of 16
-    constexpr int kRows = kWaveRows * WAVES;
-    constexpr int kWaveLhs = RG * 1024;                 // one super-stage of a wave: 64 B per row
-    constexpr int kLhsRing = 2 * WAVES * kWaveLhs;      // two super-stages
-    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
-    constexpr int kNB = PACKED ? 2 : 8;
-    constexpr int kPieces = 2 * kNB;
-    constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
-
-    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
-    const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * kWaveRows < p.rows;
-
-    // left-operand piece rg: lane 4r + j -> row 16 rg + r of this wave, stage slot j
-    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
-    const uint32_t *a_row[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        int row = mt * kRows + wave * kWaveRows + rg * 16 + ld_r;
-        if (row > p.rows - 1) row = p.rows - 1;  // clamped rows are computed but never stored
-        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
-    }
-
-    v4i acc[RG][kNB];
-    init_acc16(acc, p, lane);
-    const int r16 = lane & 15;
-    const int sh = ((lane >> 4) & 1) * 4;
-    const int swz = (r16 >> 2) & 3;
-    const int word_pair = (lane >> 5) * 8;
-
-    auto issue_lhs_piece = [&](int super_stage, int rg) {
-        int st = super_stage * 4 + ld_j;
-        if (st > stages - 1) st = stages - 1;  // past the end: re-load the last stage (never read)
-        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * kWaveLhs) + wave * kWaveLhs);
-        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
-    };
-    auto issue_lhs = [&](int super_stage) {
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) issue_lhs_piece(super_stage, rg);
-    };
-    auto issue_rhs_round = [&](int t, int buf, int j) {
-        if (t > stages - 1) t = stages - 1;
-        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        const int piece = (j * WAVES + wave) % kPieces;
-        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
-    };
-    auto issue_rhs = [&](int t, int buf) {
-#pragma unroll
-        for (int j = 0; j < kRounds; ++j) issue_rhs_round(t, buf, j);
-    };
-
-    issue_lhs(0);
-    issue_rhs(0, 0);
-    issue_rhs(1, 1);
-    int buf = 0;
-    auto stage_body = [&](auto slot_tag, auto active_tag, int t) {
-        constexpr int kSlot = decltype(slot_tag)::value;      // t mod 4
-        constexpr bool kActive = decltype(active_tag)::value;
-        // The previous iteration issued kRounds right-operand loads, plus 4 left-operand loads when it
-        // opened a super-stage; everything older has landed once only those are pending.
-        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? RG : 0)>();
-        // An active wave spreads this stage's loads between its MFMA groups (same number, same order
-        // class for the counted wait): issued in one burst right after the barrier, the four waves of
-        // the workgroup queue up at the texture addresser while their MFMA pipes sit idle.
-        constexpr bool kSpread = kActive && GSW_SPREAD_LOADS;
-        if (!kSpread) {
-            if (kSlot == 0) issue_lhs((t >> 2) + 1);
-            issue_rhs(t + 2, buf == 0 ? 2 : buf - 1);
-        }
-        if constexpr (kActive) {
-            const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * kWaveLhs) + wave * kWaveLhs + r16 * 64 +
-                                                  ((kSlot ^ swz) * 16) + word_pair);
-            const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16;
-            uint2 w[RG];
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                w[rg] = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
-            }
-            constexpr int kGroup = PACKED ? 2 : 4;
-            constexpr int kGroups = 2 * kNB / kGroup;
-            v4i fb[2][kGroup];
-            v4i fa[RG];
-#pragma unroll
-            for (int j = 0; j < kGroup; ++j) fb[0][j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
-#pragma unroll
-            for (int grp = 0; grp < kGroups; ++grp) {
-                const int cur = grp & 1;
-                if (grp + 1 < kGroups) {
-#pragma unroll
-                    for (int j = 0; j < kGroup; ++j)
-                        fb[cur ^ 1][j] = *reinterpret_cast<const v4i *>(sb + ((grp + 1) * kGroup + j) * kFragBytes);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this group's MFMAs
-                if constexpr (kSpread) {
-                    // kGroups groups carry kRounds right-operand rounds and 4 left-operand pieces
-                    constexpr int kLhsPer = RG / kGroups, kRhsPer = (kRounds + kGroups - 1) / kGroups;
-                    if (kSlot == 0) {
-#pragma unroll
-                        for (int k = 0; k < kLhsPer; ++k) issue_lhs_piece((t >> 2) + 1, grp * kLhsPer + k);
-                    }
-#pragma unroll
-                    for (int k = 0; k < kRhsPer; ++k)
-                        if (grp * kRhsPer + k < kRounds) issue_rhs_round(t + 2, buf == 0 ? 2 : buf - 1, grp * kRhsPer + k);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const int step = grp * kGroup / kNB;
-                const int f0 = grp * kGroup - step * kNB;
-                if (f0 == 0) {
-#pragma unroll
-                    for (int rg = 0; rg < RG; ++rg) {
-                        const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
-                        fa[rg][0] = (int)(y & 0x01010101u);
-                        fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-                        fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-                        fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kGroup; ++j) {
-#pragma unroll
-                    for (int rg = 0; rg < RG; ++rg)
-                        acc[rg][f0 + j] =
-                            __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[cur][j], acc[rg][f0 + j], 0, 0, 0);
-                }
-            }
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    };
-    auto main_loop = [&](auto active_tag) {
-        for (int t0 = 0; t0 < stages; t0 += 4) {
-            stage_body(std::integral_constant<int, 0>{}, active_tag, t0);
-            if (t0 + 1 < stages) stage_body(std::integral_constant<int, 1>{}, active_tag, t0 + 1);
-            if (t0 + 2 < stages) stage_body(std::integral_constant<int, 2>{}, active_tag, t0 + 2);
-            if (t0 + 3 < stages) stage_body(std::integral_constant<int, 3>{}, active_tag, t0 + 3);
-        }
-    };
-    if (wave_active) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-    // the clamped re-loads issued by the last iterations must land before this workgroup's LDS is reused
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave_active) {
-        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, PACKED, RG>(p, c, kRows, acc);
-    }
-}
-
-
-// The skewed instruction stream of gemm16_skew_body for a wave of RG row groups.
-template <int RING, int RG>
-__device__ __forceinline__ void gemm16_tall_skew_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
-                                                 unsigned char *smem) {
-    constexpr int WAVES = 4;
-    constexpr int kWaveRows = 16 * RG;             // rows of a wave: RG row groups of 16
-    constexpr int kRows = kWaveRows * WAVES;
-    constexpr int kWaveLhs = RG * 1024;            // one super-stage of a wave: 64 B per row
-    constexpr int kLhsRing = 2 * WAVES * kWaveLhs;
-    constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
-    constexpr int kNB = 8;
-    constexpr int kPieces = 2 * kNB;
-    constexpr int kRounds = kPieces / WAVES;  // 4: one per MFMA group
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
-
-    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
-    const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * kWaveRows < p.rows;
-
-    const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
-    const uint32_t *a_row[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        int row = mt * kRows + wave * kWaveRows + rg * 16 + ld_r;
-        if (row > p.rows - 1) row = p.rows - 1;
-        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
-    }
-
-    v4i acc[RG][kNB];
-    init_acc16(acc, p, lane);
-    const int r16 = lane & 15;
-    const int sh = ((lane >> 4) & 1) * 4;
-    const int swz = (r16 >> 2) & 3;
-    const int word_pair = (lane >> 5) * 8;
-
-    auto issue_lhs_piece = [&](int super_stage, int rg) {
-        int st = super_stage * 4 + ld_j;
-        if (st > stages - 1) st = stages - 1;
-        const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * kWaveLhs) + wave * kWaveLhs);
-        lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
-    };
-    auto issue_rhs_round = [&](int t, int buf, int j) {
-        if (t > stages - 1) t = stages - 1;
-        const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        const int piece = (j * WAVES + wave) % kPieces;
-        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
-    };
-    // portion q (0..3) of the loads of the stage-t epoch: right-operand round q of stage t + 2, and
-    // piece q of the next super-stage's left operand when t opens a super-stage
-    auto issue_portion = [&](int t, int buf, bool opens, int q) {
-        if (opens) {
-#pragma unroll
-            for (int k = 0; k < RG / 4; ++k) issue_lhs_piece((t >> 2) + 1, q * (RG / 4) + k);
-        }
-        issue_rhs_round(t + 2, buf == 0 ? 2 : buf - 1, q);
-    };
-    auto read_words = [&](int t, uint32_t (&wx)[RG], uint32_t (&wy)[RG]) {
-        const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * kWaveLhs) + wave * kWaveLhs + r16 * 64 +
-                                              (((t & 3) ^ swz) * 16) + word_pair);
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            const uint2 w = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
-            wx[rg] = w.x;
-            wy[rg] = w.y;
-        }
-    };
-    // keeps the compiler from sinking a fragment set's expansion below this point
-    auto pin = [&](v4i (&fa)[RG]) {
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) asm volatile("" : "+v"(fa[rg]));
-    };
-    auto expand = [&](v4i (&fa)[RG], const uint32_t (&word)[RG]) {
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            const uint32_t y = word[rg] >> sh;
-            fa[rg][0] = (int)(y & 0x01010101u);
-            fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-            fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-            fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-        }
-    };
-    auto read_frags = [&](v4i (&fb)[4], int buf, int grp) {
-        const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16 + grp * 4 * kFragBytes;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
-    };
-    auto mfma_group = [&](const v4i (&fa)[RG], const v4i (&fb)[4], int f0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg)
-                acc[rg][f0 + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[j], acc[rg][f0 + j], 0, 0, 0);
-        }
-    };
-    // 4 RG MFMAs with V vector ALU instructions after each of them (scheduler directive, no code)
-    auto interleave = [&](auto valu_tag) {
-#if GSW_SKEW_INTERLEAVE
-        constexpr int V = decltype(valu_tag)::value;
-#define GSW_SGB1                                       \
-    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);   \
-    __builtin_amdgcn_sched_group_barrier(0x2, V, 0);
-#define GSW_SGB4 GSW_SGB1 GSW_SGB1 GSW_SGB1 GSW_SGB1
-        GSW_SGB4 GSW_SGB4 GSW_SGB4 GSW_SGB4
-        if constexpr (RG == 8) { GSW_SGB4 GSW_SGB4 GSW_SGB4 GSW_SGB4 }
-#undef GSW_SGB4
-#undef GSW_SGB1
-#endif
-    };
-
-    // prologue: left operand of super-stage 0, right operand of stages 0 and 1
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) issue_lhs_piece(0, rg);
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(0, 0, j);
-#pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, 1, j);
-
-    v4i fa0[RG], fa1[RG], fbA[4], fbB[4];
-    uint32_t wy[RG];  // the second words (MFMA step 1) of the current stage
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) wy[rg] = 0u;
-    int buf = 0;
-
-    auto stage = [&](auto slot_tag, auto first_tag, auto active_tag, int t) {
-        constexpr int kSlot = decltype(slot_tag)::value;
-        constexpr bool kFirst = decltype(first_tag)::value;
-        constexpr bool kActive = decltype(active_tag)::value;
-        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? RG : 0)>();
-        const bool opens = kSlot == 0;
-        if constexpr (!kActive) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) issue_portion(t, buf, opens, q);
-        } else {
-            if constexpr (kFirst) {
-                uint32_t wx[RG];
-                read_words(t, wx, wy);
-                expand(fa0, wx);
-            }
-            // phase 0: first fragments of this stage; the previous stage's last group covers their latency
-            read_frags(fbA, buf, 0);
-            issue_portion(t, buf, opens, 0);
-            if constexpr (!kFirst) {
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_group(fa1, fbB, 4);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 1: step 0, fragments 0..3; the step-1 fragments of this stage are expanded meanwhile
-            read_frags(fbB, buf, 1);
-            issue_portion(t, buf, opens, 1);
-            mfma_group(fa0, fbA, 0);
-            expand(fa1, wy);
-            pin(fa1);
-            interleave(std::integral_constant<int, 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 2: step 0, fragments 4..7; the next stage's left-operand words are fetched
-            read_frags(fbA, buf, 2);
-            issue_portion(t, buf, opens, 2);
-            mfma_group(fa0, fbB, 4);
-            uint32_t nx[RG], ny[RG];
-            read_words(t + 1, nx, ny);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 3: step 1, fragments 0..3; the next stage's step-0 fragments are expanded
-            read_frags(fbB, buf, 3);
-            issue_portion(t, buf, opens, 3);
-            mfma_group(fa1, fbA, 0);
-            expand(fa0, nx);
-            pin(fa0);
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg) wy[rg] = ny[rg];
-            interleave(std::integral_constant<int, 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-            // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    };
-    auto main_loop = [&](auto active_tag) {
-        stage(std::integral_constant<int, 0>{}, std::true_type{}, active_tag, 0);
-        if (1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, 1);
-        if (2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, 2);
-        if (3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, 3);
-        for (int t0 = 4; t0 < stages; t0 += 4) {
-            stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, t0);
-            if (t0 + 1 < stages) stage(std::integral_constant<int, 1>{}, std::false_type{}, active_tag, t0 + 1);
-            if (t0 + 2 < stages) stage(std::integral_constant<int, 2>{}, std::false_type{}, active_tag, t0 + 2);
-            if (t0 + 3 < stages) stage(std::integral_constant<int, 3>{}, std::false_type{}, active_tag, t0 + 3);
-        }
-    };
-    if (wave_active) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave_active) {
-        mfma_group(fa1, fbB, 4);  // the last stage's deferred group
-        const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, false, RG>(p, c, kRows, acc);
-    }
-}
-
-
-template <int RING, int RG>
-__global__ __launch_bounds__(256, 1) void binlimb_gemm16_tall(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                              int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_tall_body<RING, RG, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_tall_body<RING, RG, false>(p, ell, mask, b, nt, mt, smem);
-}
-
-template <int RING, int RG>
-__global__ __launch_bounds__(256, 1) void binlimb_gemm16_tall_skew(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                                   int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) gemm16_tall_body<RING, RG, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_tall_skew_body<RING, RG>(p, ell, mask, b, nt, mt, smem);
-}
-
-#endif  // GSW_EXP_TALL
 
 // ---- Skewed 256-row pipeline (full column tiles).
 //
