@@ -2,12 +2,14 @@
 (F_p or Z/2^M for any M in 1..32), random n, random batch, entries laid out with random gaps between them, mult or
 nand, products through the batch call, the prepared-operand call and a gate list.  Bit exact, every entry compared.
 The seeds are fixed, so a failure names a case that fails again."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = 48
+CASES = int(os.environ.get("GSW_FUZZ_CASES", "48"))  # a soak run sets more; the suite runs the first 48
 
 
 @pytest.fixture(scope="module")
