@@ -138,7 +138,7 @@ struct gsw_ctx {
     void *small;         // scratch of the helpers that return values to the host (row dots, tables, staging)
     size_t small_bytes;
     int gemm_variant;
-    bool packed_tail;  // the last column tile of prepared operands is stored packed
+    int packed_tail;  // how the last column tile of prepared operands is stored (gswk::tail_mode)
     bool timing;
     std::vector<TimedLaunch> timed[2];
     // slot lists of gsw_eval_circuit: pinned host staging, device copy, event marking the upload's end
@@ -354,7 +354,8 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
         return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 9 (default), 2 or 3 (simple cross-check kernels); the "
                                    "superseded kernels exist only in a -DGSW_DIAGNOSTIC_BUILDS library");
     }
-    ctx->packed_tail = ctx->gemm_variant != 2 && ctx->gemm_variant != 3 && gswk::can_pack_tail(ctx->width);
+    ctx->packed_tail = (ctx->gemm_variant == 2 || ctx->gemm_variant == 3) ? gswk::kTailNone
+                                                                          : gswk::tail_mode(ctx->width, ctx->gemm_variant == 9);
     if (int rc = resolve_static_scratch(device, &ctx->static_scratch)) {  // `device` is current (hipSetDevice above)
         delete ctx;
         return rc;
@@ -722,7 +723,7 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
     if (d_out == d_c1 || d_out == d_c2) return fail(GSW_E_INVALID, "output must not alias an input");
     if (int rc = use_device(ctx)) return rc;
     ctx->last_dense_path = 0;
-    const bool packed_tail = ctx->gemm_variant == 9 && gswk::can_pack_tail(dim);
+    const int packed_tail = ctx->gemm_variant == 9 ? gswk::tail_mode(dim, true) : gswk::kTailNone;
     const size_t prep = gswk::prepared_bytes(dim, ctx->e4, packed_tail);
     // below about a thousand rows the detection pass and its host synchronisation cost more than the plain
     // kernel takes (N = 341: 0.06 ms against 0.02 ms); dense_fast == 2 takes the MFMA path at any size

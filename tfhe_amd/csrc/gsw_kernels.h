@@ -46,7 +46,7 @@ struct GemmArgs {
     int ld_out;
     int batch;
     int mode;
-    int packed_tail;              // the last column tile is a packed one (see prepared_bytes)
+    int packed_tail;              // the last column tile is a packed one: kTailPacked / kTailNarrow (see tail_mode)
     int pass_rows, pass_cols;     // placement passes of the blocked workgroup order (row tiles x column tiles)
     unsigned long long *digests;  // optional: digests[b] += digest of the stored tile (zeroed by the caller)
     // optional slot lists (device, `batch` entries): entry b reads lhs + lhs_slot[b] * lhs_stride and
@@ -67,6 +67,17 @@ inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCo
 // A last column tile with at most 8 valid columns can be stored packed: one fragment per K element
 // whose MFMA column 8 l + c carries limb l of column c (a quarter of the MFMA work of a full tile).
 inline bool can_pack_tail(int out_cols) { return out_cols % kTileCols >= 1 && out_cols % kTileCols <= 8; }
+// How the last column tile of a prepared operand is stored.  kTailPacked: at most 8 valid columns, 32 MFMA columns
+// (two accumulators per row group), MFMA column 8 l + c carries limb l of column c.  kTailNarrow: at most 4 valid
+// columns, 16 MFMA columns (one accumulator, half the MFMAs), MFMA column 4 l + c; one fragment per MFMA step, the
+// stages 2 KiB apart.  Only the default kernel reads the narrow form (narrow_ok).
+constexpr int kTailNone = 0, kTailPacked = 1, kTailNarrow = 2;
+inline int tail_mode(int out_cols, bool narrow_ok) {
+    const int r = out_cols % kTileCols;
+    if (r >= 1 && r <= 4 && narrow_ok) return kTailNarrow;
+    return can_pack_tail(out_cols) ? kTailPacked : kTailNone;
+}
+// (the narrow form leaves part of the packed tile's space unused)
 inline size_t prepared_bytes(int out_cols, int e4, bool packed_tail) {
     const size_t frags = (size_t)col_tiles(out_cols) * 4 - (packed_tail ? 3 : 0);
     return frags * e4 * kFragBytes;
@@ -86,7 +97,7 @@ struct PrepArgs {
     int elems;  // valid K elements (rows_valid = elems * ell)
     int e4;
     int batch;
-    int packed_tail;
+    int packed_tail;  // kTailNone / kTailPacked / kTailNarrow
     int layout16;  // fragment order of the 16x16x64 kernels (variants 4, 5) instead of the 32x32x32 ones
     const uint32_t *src_slot;  // optional slot list (device, `batch` entries) into src; null means slot b
     const uint32_t *dst_slot;  // optional slot list into dst (a cache of prepared operands); null means slot b

@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
     const int t = blockIdx.x >> 1, step = blockIdx.x & 1, nt = blockIdx.y, b = blockIdx.z;
     const int cidx = tid & 31, i = (tid >> 5) & 3, h = tid >> 7;
     const bool packed = a.packed_tail && nt == (int)gridDim.y - 1;
+    const bool narrow = packed && a.packed_tail == kTailNarrow;  // 16 MFMA columns: 4 l + c
     const uint32_t *src = a.src + (size_t)slot_of(a.src_slot, b) * a.src_stride;
-    const int col = nt * kTileCols + (packed ? (cidx & 7) : cidx);
+    const int col = nt * kTileCols + (narrow ? (cidx & 3) : packed ? (cidx & 7) : cidx);
 #pragma unroll
     for (int gh = 0; gh < 2; ++gh) {
         const int e = 4 * t + 2 * gh + step;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
         const int g = 2 * gh + h;
         const int cg = cidx >> 4, c16 = cidx & 15;
         if (packed) {
-            const int l = cidx >> 3;
+            const int l = narrow ? (cidx >> 2) & 3 : cidx >> 3;
             tile[(cg * 64 + g * 16 + c16) * 4 + i] = l == 0 ? limb[0] : l == 1 ? limb[1] : l == 2 ? limb[2] : limb[3];
         } else {
 #pragma unroll
@@ -176,7 +177,14 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
     }
     __syncthreads();
     uint8_t *dst = a.dst + slot_of(a.dst_slot, b) * a.dst_stride + (size_t)nt * a.e4 * (4 * kFragBytes);
-    if (packed) {
+    if (narrow) {
+        // one fragment (column group 0) per MFMA step; the other half of the tile's space is kept zero so that
+        // equal operands have equal prepared images
+        if (tid < 64)
+            reinterpret_cast<uint4 *>(dst + (size_t)blockIdx.x * kFragBytes)[tid] = reinterpret_cast<const uint4 *>(tile)[tid];
+        else if (tid < 128)
+            reinterpret_cast<uint4 *>(dst + (size_t)(gridDim.x + blockIdx.x) * kFragBytes)[tid - 64] = make_uint4(0u, 0u, 0u, 0u);
+    } else if (packed) {
         if (tid < 128)
             reinterpret_cast<uint4 *>(dst + (size_t)blockIdx.x * (2 * kFragBytes))[tid] =
                 reinterpret_cast<const uint4 *>(tile)[tid];
@@ -405,14 +413,14 @@ __device__ __forceinline__ void digest_commit(const GemmArgs &p, int b, int lane
 
 // Start values of the accumulators (GemmArgs::acc_init): limb l of a full tile sits in accumulators 2 l and
 // 2 l + 1 of a row group; in a packed tail tile accumulator f carries limb 2 f + (column >> 3) in MFMA column
-// 8 (limb & 1) + c.
+// 8 (limb & 1) + c; in a narrow one the single accumulator carries limb l in MFMA column 4 l + c.
 template <int RG, int NB>
 __device__ __forceinline__ void init_acc16(v4i (&acc)[RG][NB], const GemmArgs &p, int lane) {
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
         for (int f = 0; f < NB; ++f) {
-            const int v = (int)(NB == 8 ? p.acc_init[f >> 1] : p.acc_init[2 * f + ((lane >> 3) & 1)]);
+            const int v = (int)(NB == 8 ? p.acc_init[f >> 1] : NB == 2 ? p.acc_init[2 * f + ((lane >> 3) & 1)] : p.acc_init[(lane >> 2) & 3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[rg][f][r] = v;
         }
@@ -479,9 +487,10 @@ __device__ __forceinline__ void gemm16_epilogue_interior(const GemmArgs &p, cons
     if (DIGEST) digest_commit(p, c.b, lane, dig);
 }
 
-template <int RING, bool PACKED, int RG = 4>
+// PACKED: kTailNone (a full tile: 8 accumulators per row group), kTailPacked (2), kTailNarrow (1)
+template <int RING, int PACKED, int RG = 4>
 __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx &c, int tile_rows,
-                                                const v4i (&acc)[RG][PACKED ? 2 : 8]) {
+                                                const v4i (&acc)[RG][PACKED == 0 ? 8 : PACKED == 1 ? 2 : 1]) {
     const int lane = c.lane, quad = lane >> 4, c16 = lane & 15;
     const uint32_t addend = (p.mode == kModeEncrypt) ? p.addend[c.b] : 0u;
     uint32_t *out = p.out + (size_t)slot_of(p.out_slot, c.b) * p.out_stride;
@@ -491,7 +500,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int f = 0; f < (PACKED ? 2 : 8); ++f)
+            for (int f = 0; f < (PACKED == 0 ? 8 : PACKED == 1 ? 2 : 1); ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x ^= acc[rg][f][r];
         const int row = c.mt * tile_rows + c.wave * (16 * RG) + quad;
@@ -532,14 +541,15 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                 int col;
                 bool owner;
                 if (!PACKED) {
-                    s0 = (uint32_t)acc[rg][(0 * 2 + cg) % (PACKED ? 2 : 8)][r];
-                    s1 = (uint32_t)acc[rg][(1 * 2 + cg) % (PACKED ? 2 : 8)][r];
-                    s2 = (uint32_t)acc[rg][(2 * 2 + cg) % (PACKED ? 2 : 8)][r];
-                    s3 = (uint32_t)acc[rg][(3 * 2 + cg) % (PACKED ? 2 : 8)][r];
+                    constexpr int kAll = PACKED == 0 ? 8 : 1;  // (index folded for the other instantiations)
+                    s0 = (uint32_t)acc[rg][(0 * 2 + cg) % kAll][r];
+                    s1 = (uint32_t)acc[rg][(1 * 2 + cg) % kAll][r];
+                    s2 = (uint32_t)acc[rg][(2 * 2 + cg) % kAll][r];
+                    s3 = (uint32_t)acc[rg][(3 * 2 + cg) % kAll][r];
                     col = c.nt * kTileCols + cg * 16 + c16;
                     owner = true;
-                } else {
-                    const int v0 = acc[rg][0][r], v1 = acc[rg][1][r];
+                } else if (PACKED == kTailPacked) {
+                    const int v0 = acc[rg][0][r], v1 = acc[rg][PACKED == kTailPacked ? 1 : 0][r];
                     const int base = (lane & 48) | (lane & 7);
                     s0 = (uint32_t)__shfl(v0, base, 64);
                     s1 = (uint32_t)__shfl(v0, base + 8, 64);
@@ -547,6 +557,16 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
                     s3 = (uint32_t)__shfl(v1, base + 8, 64);
                     col = c.nt * kTileCols + (c16 & 7);
                     owner = c16 < 8;
+                } else {
+                    // narrow tile: limb l of column cc sits in MFMA column 4 l + cc of the one accumulator
+                    const int v0 = acc[rg][0][r];
+                    const int base = (lane & 48) | (lane & 3);
+                    s0 = (uint32_t)__shfl(v0, base, 64);
+                    s1 = (uint32_t)__shfl(v0, base + 4, 64);
+                    s2 = (uint32_t)__shfl(v0, base + 8, 64);
+                    s3 = (uint32_t)__shfl(v0, base + 12, 64);
+                    col = c.nt * kTileCols + (c16 & 3);
+                    owner = c16 < 4;
                 }
                 uint32_t val = ring_from_u64<RING>(s0 + (s1 << 8) + (s2 << 16) + (s3 << 24), c.mask);
                 if (owner && row < p.rows && col < p.ld_out) {
@@ -574,7 +594,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
 #pragma unroll
                 for (int extra = 0; extra < 2; ++extra) {
                     const int zc = c.nt * kTileCols + extra * 16 + c16;
-                    if ((extra == 1 || c16 >= 8) && zc < p.ld_out) {
+                    if ((extra == 1 || c16 >= (PACKED == kTailNarrow ? 4 : 8)) && zc < p.ld_out) {
                         const size_t idx = (size_t)row * p.ld_out + zc;
                         out[idx] = 0u;
                         if (want_digest) dig += 2u * (unsigned)idx + 1u;
@@ -623,13 +643,15 @@ __device__ __forceinline__ uint2 lds_read_b64_alone(uint32_t lds_byte_address) {
 template <int WAVES>
 constexpr int rowblock_lds_bytes() { return 2 * WAVES * 4096 + kPipeBuffers * kStageElems * 4 * kFragBytes; }
 
-template <int RING, int WAVES, bool PACKED>
+// PACKED: kTailNone (full tile), kTailPacked (tail tile of 32 MFMA columns), kTailNarrow (of 16: its stages are
+// two fragments, 2 KiB apart in the prepared operand).
+template <int RING, int WAVES, int PACKED>
 __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
                                                      int mt, unsigned char *smem) {
     constexpr int kRows = 64 * WAVES;
     constexpr int kLhsRing = 2 * WAVES * 4096;          // two super-stages of 64 B per row
     constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
-    constexpr int kNB = PACKED ? 2 : 8;
+    constexpr int kNB = PACKED == kTailNone ? 8 : PACKED == kTailPacked ? 2 : 1;
     constexpr int kPieces = 2 * kNB;
     constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
 
@@ -710,7 +732,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
             for (int rg = 0; rg < 4; ++rg) {
                 w[rg] = lds_read_b64_alone(sa + (uint32_t)(rg * 1024));
             }
-            constexpr int kGroup = PACKED ? 2 : 4;
+            constexpr int kGroup = PACKED == kTailNone ? 4 : kNB;  // a packed tile: one group per MFMA step
             constexpr int kGroups = 2 * kNB / kGroup;
             v4i fb[2][kGroup];
             v4i fa[4];
@@ -1028,8 +1050,12 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
 #ifdef GSW_EXP_PRIO
     if (second) __builtin_amdgcn_s_setprio(GSW_EXP_PRIO);
 #endif
-    if (p.packed_tail && nt == nt_count - 1) gemm16_rowblock_body<RING, 4, true>(p, ell, mask, b, nt, mt, smem);
-    else gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
+    if (p.packed_tail && nt == nt_count - 1) {
+        if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow>(p, ell, mask, b, nt, mt, smem);
+        else gemm16_rowblock_body<RING, 4, kTailPacked>(p, ell, mask, b, nt, mt, smem);
+    } else {
+        gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
+    }
 }
 
 // Superseded contraction kernels (variants 0, 1, 4..8) and timing-only ablation builds: compiled only into
