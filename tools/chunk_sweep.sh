@@ -2,7 +2,7 @@
 # whole-job rate of the default bench against the chunk of the preparation / contraction pipeline
 mkdir -p gpurun_out
 for i in 1 2; do
-for c in 64 96 128 192 256 0; do
+for c in ${CHUNKS:-64 96 128 192 256 0}; do
   GSW_OVERLAP_CHUNK=$c timeout -k 10 200 python bench.py --no-cpu-baseline --steps 4 "$@" > gpurun_out/cs.json 2> gpurun_out/cs.err || { tail -5 gpurun_out/cs.err; exit 1; }
   python - "$c" <<'PY'
 import json, sys
