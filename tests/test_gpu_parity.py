@@ -50,8 +50,8 @@ def _assert_equal(got, expect, what):
 # ---------------------------------------------------------------- the hot path, small shapes
 # kernel variants of the shipped library: 9 = the default (16x16x64 MFMA, skewed pipeline, packed tail tile),
 # 2 / 3 = the simple two-buffer 32x32x32 kernels (LDS-DMA / register staging), an independent cross-check.
-# n + 1 columns: 2, 4, 8 (a packed tile only), 11, 33/34/40 (full + packed tail), 41 (full + unpacked tail),
-# 72 (two full + packed tail of 8)
+# n + 1 columns: 2, 4 (a narrow tile only), 8 (a packed tile only), 11, 33/34/35/36 (full + narrow tail), 37/40 (full +
+# packed tail), 41 (full + unpacked tail), 67 (two full + narrow tail), 72 (two full + packed tail of 8)
 VARIANTS = ["2", "3", "9"]
 
 
@@ -60,7 +60,9 @@ VARIANTS = ["2", "3", "9"]
                                           ("fp", 40), ("fp", 71), ("z30", 10), ("z31", 10), ("z32", 10),
                                           ("z32", 33), ("z8", 5), ("z2", 9), ("z1", 40),
                                           # last row tile of at most 64 rows (the thin-tile path of variant 9)
-                                          ("fp", 8), ("fp", 16), ("z32", 8)])
+                                          ("fp", 8), ("fp", 16), ("z32", 8),
+                                          # tail tiles of 2, 3, 4 columns (stored narrow: 16 MFMA columns) and of 5 (packed: 32)
+                                          ("fp", 33), ("fp", 34), ("z32", 35), ("fp", 36), ("z31", 66)])
 def test_mul_gadget_random_operands(oracle, tfhe_amd, ring_name, n, variant):
     """Pc = BitDecomp(C1c) * C2c on uniform random operands (every bit pattern exercised)."""
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
