@@ -812,3 +812,27 @@ def test_n256_rows_with_the_64_bit_recombination(oracle, tfhe_amd):
     rows = np.concatenate([np.arange(0, 4), rng.integers(0, ring_o.big_n(n), 24), np.arange(ring_o.big_n(n) - 4, ring_o.big_n(n))])
     for r in rows:
         _assert_equal(wide[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")
+
+
+def test_n1024_takes_the_64_bit_recombination_natively(oracle, tfhe_amd):
+    """n = 1024: 32 896 K slots, beyond the bound of the 32-bit recombination, so the contraction takes start values
+    below 2^28 and the 64-bit form by itself; the shape also has a one-column (narrow) tail tile, a thin last row tile
+    and a half last stage.  Sampled rows of one product against the oracle."""
+    import ctypes as C
+    from tfhe_amd import _lib
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 1024
+    out4, lean = (C.c_uint32 * 4)(), C.c_int(-1)
+    _lib.check(_lib.lib().gsw_diag_limb_start_values(_lib.RING_FP_M31, 31, 32 * ((n + 1 + 3) // 4 * 4), 0, out4, C.byref(lean)))
+    assert lean.value == 0
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
+    og = oracle.GSW(ring_o, n, n * 31)
+    rng = np.random.default_rng(1024)
+    c1, c2 = _rand_compact(rng, ring_o, n), _rand_compact(rng, ring_o, n)
+    c1[5] = P - 1  # a row of (almost) all ones: the largest limb sums
+    got = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1), tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    big_n = ring_o.big_n(n)
+    rows = np.concatenate([np.arange(0, 8), rng.integers(0, big_n, 16), np.arange(big_n - 40, big_n, 5)])
+    for r in rows:
+        _assert_equal(got[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")
