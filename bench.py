@@ -38,11 +38,8 @@ from tfhe_amd import _lib, dist as gdist  # noqa: E402
 
 INT8_DENSE_PEAK_TOPS = 5033.0  # 256 CU x 4 SIMD x 2048 int8 ops/clk x 2.4 GHz (2x the bf16 dense MFMA peak)
 HBM_PEAK_GBS = 8000.0
-KERNEL_NAMES = {0: "binlimb_gemm_pipelined<4 waves>", 1: "binlimb_gemm_pipelined<8 waves>",
-                2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>",
-                4: "binlimb_gemm16_pipelined<4 waves>", 5: "binlimb_gemm16_pipelined<8 waves>",
-                6: "binlimb_gemm16_rowblock<4 waves>", 7: "binlimb_gemm16_rowblock<8 waves>",
-                8: "binlimb_gemm16_stagger", 9: "binlimb_gemm16_skew"}
+# the contraction kernels of the shipped library (a -DGSW_DIAGNOSTIC_BUILDS library also accepts the superseded ones)
+KERNEL_NAMES = {2: "binlimb_gemm_kernel<dma>", 3: "binlimb_gemm_kernel<regs>", 9: "binlimb_gemm16_skew"}
 
 WORKLOADS = {
     # name: (ring, n, default batch)
@@ -80,7 +77,7 @@ def parse_args():
                          "by the root's xGMI / PCIe ingress, not by the kernels)")
     ap.add_argument("--diag-pool", choices=["uniform", "zero", "sparse"], default="uniform",
                     help="diagnostic: operand data pattern (anything but uniform is not the benchmark)")
-    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant 0..8 (default: chosen by shape)")
+    ap.add_argument("--variant", type=int, default=None, help="contraction kernel variant: 9 (default), 2 or 3 (the simple cross-check kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target CPU work for the baseline sample")
     return ap.parse_args()
@@ -160,16 +157,58 @@ def cpu_baseline(engine, ring, n, pool_t, lhs_idx, rhs_idx, out_t, seconds: floa
     }
 
 
+def spawn_ranks(n_ranks: int, rehearsal: bool) -> int:
+    """`bench.py --gpus N` started bare (no torch.distributed.run around it): this process touches no GPU, starts one
+    child per rank with the rendezvous environment set, lets them print (rank 0 prints the JSON line) and returns
+    the first non-zero exit status, ending the other ranks when one fails."""
+    import socket
+    import subprocess
+
+    visible = torch.cuda.device_count()  # counts devices without initialising one
+    if visible < n_ranks and not rehearsal:
+        print(f"bench.py: --gpus {n_ranks} but {visible} GPU(s) visible; one rank per GPU is the only mode "
+              "(GSW_BENCH_REHEARSAL=1 puts every rank on GPU 0 over gloo to rehearse the control flow)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            rc = children[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    children[o].terminate()  # the exact processes started above
+        time.sleep(0.05)
+    return status
+
+
 def main():
     args = parse_args()
     # GSW_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo, to exercise the multi-rank control flow on a
     # one-GPU box (RCCL refuses two ranks on one device); its numbers are not a measurement
     rehearsal = os.environ.get("GSW_BENCH_REHEARSAL") == "1"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: make the N ranks here, before anything in this process touches a GPU
+        raise SystemExit(spawn_ranks(args.gpus, rehearsal))
     rank, local_rank, world = gdist.init("gloo" if rehearsal else None)
     if rehearsal:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -304,6 +343,7 @@ def run(args, gsw, ring, n, batch, pool_default, variant, rank, world, dev, rehe
                    "benchmark_config": args.config or (2 if args.workload == "fp_n256" and batch == 1024 else None),
                    "batch_per_gpu": batch, "pool": pool, "gather": args.gather,
                    "exchange_verified": exchange_ok,
+                   "world_size_seen": gdist.world_size_seen(), "backend": gdist.backend_name(),
                    "parallelism": f"batch-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else "")},
         "roofline": {
             "bound": "mfma", "achieved": achieved_tops, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TOP/s",

@@ -131,6 +131,11 @@ int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uin
 int gsw_ctx_set_dense_fast(gsw_ctx *ctx, int enable);
 /* which kernel the last dense product of this context used: 0 = plain dim^3, 1 = MFMA contraction */
 int gsw_ctx_last_dense_path(const gsw_ctx *ctx);
+/* Test aid, no counterpart in the reference.  How the last contraction launch of this context recombined its four
+ * limb sums: 1 = the 32-bit form with the branch-free epilogue on interior tiles (every benchmark shape), 0 = the
+ * general epilogue with the 64-bit form on every tile (contractions too long for the 32-bit bound, or
+ * GSW_FORCE_WIDE_COMBINE=1 in the environment), -1 = no launch yet. */
+int gsw_ctx_last_combine(const gsw_ctx *ctx);
 
 /* ---- the hot path: Pc = G^-1(C1c) * C2c mod q on int8 MFMA (gsw_impl.rs:104-123 via the
  *      identity above).  Strides are in uint32 elements between consecutive batch entries;
@@ -168,8 +173,10 @@ int gsw_mul_gadget_batch_digest(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
  * in chunks of floor(GSW_STATIC_SCRATCH_BYTES / gsw_ctx_prepared_bytes()) on the context's stream, one
  * after another, so any batch length is accepted; a context whose single prepared operand exceeds the
  * array (n above 512 for Fp) is refused with GSW_E_UNSUPPORTED.  Kernel timing (gsw_ctx_enable_timing)
- * does not cover this call.  Every context on a GPU shares that GPU's array: calls that overlap in time
- * on one GPU (two contexts, two streams, two threads) race on it -- serialise them. */
+ * does not cover this call.  Every context on a GPU shares that GPU's array: the library orders its users -- a
+ * call's stream first waits (hipStreamWaitEvent on a per-GPU event made at gsw_ctx_create) for the last contraction
+ * of the call before it, whichever context or stream that was -- so calls from several contexts or threads queue
+ * up on the array instead of racing on it; they do not overlap on the GPU. */
 #define GSW_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
 int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, const uint32_t *d_c2c,
                                 size_t stride2, uint32_t *d_out, size_t stride_out, int batch, unsigned flags);

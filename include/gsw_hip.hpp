@@ -196,6 +196,9 @@ class GSW {
         CompactCiphertext x = encrypt_compact(pk, 0);  // R * pk in compact form (message 0)
         DMatrix c = to_dense(x, 0);
         for (int i = 0; i < c.cols; ++i) c(i, i) = ring_add(c(i, i), message);  // :34-36
+#ifdef GSW_USE_FLATTEN  // the reference's cargo feature use_flatten (Cargo.toml:16-17): gsw_impl.rs:38-39
+        flatten_matrix(c);
+#endif
         return c;
     }
 
@@ -246,6 +249,9 @@ class GSW {
         check(gsw_add(ctx_, a.u32(), b.u32(), a.u32(), c1.data.size()));
         DMatrix out(c1.rows, c1.cols);
         a.download(out.data.data(), out.data.size() * 4);
+#ifdef GSW_USE_FLATTEN  // gsw_impl.rs:91-92
+        flatten_matrix(out);
+#endif
         return out;
     }
 
@@ -254,6 +260,20 @@ class GSW {
         a.upload(c.data.data(), c.data.size() * 4);
         check(gsw_mult_const(ctx_, a.u32(), constant, c.data.size()));
         a.download(c.data.data(), c.data.size() * 4);
+#ifdef GSW_USE_FLATTEN  // gsw_impl.rs:99-100
+        flatten_matrix(c);
+#endif
+    }
+
+    // flatten_matrix (helper.rs:58-62), computed on the GPU, in place on a host matrix
+    void flatten_matrix(DMatrix &c) {
+        if (c.cols % R::Num_Bits) throw std::runtime_error("flatten needs a column count that is a multiple of Num_Bits");
+        DeviceBuffer d(ctx_, c.data.size() * 4);
+        std::vector<uint32_t> rm = c.row_major();
+        d.upload(rm.data(), rm.size() * 4);
+        check(gsw_flatten(ctx_, d.u32(), c.rows, c.cols / R::Num_Bits));
+        d.download(rm.data(), rm.size() * 4);
+        c = DMatrix::from_row_major(c.rows, c.cols, rm);
     }
 
     // A left operand in the reference's own ciphertext format (0 / 1 off the diagonal) takes the int8-MFMA
@@ -386,6 +406,9 @@ class GSW {
         b.upload(rb.data(), count * 4);
         check(is_nand ? gsw_nand_dense(ctx_, a.u32(), b.u32(), o.u32(), c1.rows)
                       : gsw_mul_dense(ctx_, a.u32(), b.u32(), o.u32(), c1.rows));
+#ifdef GSW_USE_FLATTEN  // gsw_impl.rs:108-109,120-121
+        if (c1.cols % R::Num_Bits == 0) check(gsw_flatten(ctx_, o.u32(), c1.rows, c1.cols / R::Num_Bits));
+#endif
         std::vector<uint32_t> ro(count);
         o.download(ro.data(), count * 4);
         return DMatrix::from_row_major(c1.rows, c1.cols, ro);

@@ -68,6 +68,8 @@ extern "C" {
     fn gsw_add(ctx: *mut gsw_ctx, a: *const u32, b: *const u32, out: *mut u32, count: usize) -> c_int;
     fn gsw_ctx_set_dense_fast(ctx: *mut gsw_ctx, enable: c_int) -> c_int;
     fn gsw_ctx_last_dense_path(ctx: *const gsw_ctx) -> c_int;
+    fn gsw_ctx_last_combine(ctx: *const gsw_ctx) -> c_int;
+    fn gsw_flatten(ctx: *mut gsw_ctx, d_mat: *mut u32, rows: c_int, cols: c_int) -> c_int;
     fn gsw_ctx_prepared_bytes(ctx: *const gsw_ctx) -> usize;
     fn gsw_eval_circuit_cached(ctx: *mut gsw_ctx, d_pool: *mut u32, slot_stride: usize, n_slots: u32, d_prepared_pool: *mut c_void, h_valid: *mut u8, gates: *const gsw_gate, n_gates: usize) -> c_int;
     fn gsw_keygen_device(ctx: *mut gsw_ctx, seed: u64, first_stream: u64, sampler: c_int, sigma: f64, unchecked: c_int, h_t_out: *mut u32, d_pk_matrix_out: *mut u32, d_pk_prepared: *mut c_void) -> c_int;
@@ -227,6 +229,21 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> GswHip<R, T> {
     pub fn last_dense_path(&self) -> i32 {
         unsafe { gsw_ctx_last_dense_path(self.ctx) }
     }
+    /// How the last contraction launch recombined its limb sums (1 = 32-bit form, 0 = 64-bit form, -1 = none yet).
+    pub fn last_combine(&self) -> i32 {
+        unsafe { gsw_ctx_last_combine(self.ctx) }
+    }
+    /// flatten_matrix (helper.rs:58-62) on a host matrix, computed on the GPU: what the reference applies to the
+    /// result of encrypt / add / mult_const / mult / nand under its `use_flatten` feature (Cargo.toml:16-17).
+    #[cfg(feature = "use_flatten")]
+    fn flatten_matrix(&self, c: &mut DMatrix<R>) {
+        let (rows, cols) = (c.nrows(), c.ncols());
+        let ell = R::Num_Bits as usize;
+        assert_eq!(cols % ell, 0, "flatten needs a column count that is a multiple of Num_Bits");
+        let d = Dev::from_host(self.ctx, &Self::to_rows(c));
+        ok(unsafe { gsw_flatten(self.ctx, d.u32(), rows as c_int, (cols / ell) as c_int) });
+        *c = Self::from_rows(rows, cols, &d.to_host(rows * cols));
+    }
     pub fn set_dense_mode(&self, mode: i32) {
         ok(unsafe { gsw_ctx_set_dense_fast(self.ctx, mode) });
     }
@@ -289,6 +306,8 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
         for i in 0..product.ncols() {
             product[(i, i)] += message;
         }
+        #[cfg(feature = "use_flatten")] // gsw_impl.rs:38-39
+        self.flatten_matrix(&mut product);
         product
     }
 
@@ -315,10 +334,16 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
     // (gsw_add / gsw_mult_const serve device-resident ciphertexts)
     fn add(&self, a: &Self::Ciphertext, b: &Self::Ciphertext) -> Self::Ciphertext {
         Self::same_size(a, b);
-        a + b
+        #[allow(unused_mut)]
+        let mut res = a + b;
+        #[cfg(feature = "use_flatten")] // gsw_impl.rs:91-92
+        self.flatten_matrix(&mut res);
+        res
     }
     fn mult_const(&self, c: &mut Self::Ciphertext, constant: R) {
         *c *= constant;
+        #[cfg(feature = "use_flatten")] // gsw_impl.rs:99-100
+        self.flatten_matrix(c);
     }
 
     // gsw_impl.rs:104-111 (default features).  A left operand in the reference's own ciphertext format --
@@ -326,11 +351,19 @@ impl<R: HipRing + 'static, T: ErrorSampling<R>> FheScheme<R> for GswHip<R, T> {
     // gsw_mul_dense (3.3 ms against 78 ms at N = 7967); any other entries take the plain N^3 kernel.
     fn mult(&self, a: &Self::Ciphertext, b: &Self::Ciphertext) -> Self::Ciphertext {
         Self::same_size(a, b);
-        self.dense_binary(gsw_mul_dense, a, b)
+        #[allow(unused_mut)]
+        let mut res = self.dense_binary(gsw_mul_dense, a, b);
+        #[cfg(feature = "use_flatten")] // gsw_impl.rs:108-109
+        self.flatten_matrix(&mut res);
+        res
     }
     // gsw_impl.rs:114-123
     fn nand(&self, a: &Self::Ciphertext, b: &Self::Ciphertext) -> Self::Ciphertext {
-        self.dense_binary(gsw_nand_dense, a, b)
+        #[allow(unused_mut)]
+        let mut res = self.dense_binary(gsw_nand_dense, a, b);
+        #[cfg(feature = "use_flatten")] // gsw_impl.rs:120-121
+        self.flatten_matrix(&mut res);
+        res
     }
 }
 

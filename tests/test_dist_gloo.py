@@ -109,3 +109,23 @@ def test_result_drain_gathers_every_entry_in_chunks(tmp_path):
     base = np.arange(7 * 15, dtype=np.int32).reshape(7, 5, 3)
     assert got.shape == (2, 7, 5, 3)
     assert np.array_equal(got[0], base) and np.array_equal(got[1], base + 1000)
+
+
+def test_bench_never_reports_fewer_ranks_than_asked_for():
+    """`bench.py --gpus N` either runs N ranks or fails: bare on a box with fewer GPUs it refuses before touching a
+    device; under a launcher whose WORLD_SIZE disagrees it refuses too.  No JSON line in either case."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box would really run the two ranks")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GSW_BENCH_REHEARSAL")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+    bare = subprocess.run(cmd, cwd=root, env=base, capture_output=True, text=True, timeout=120)
+    assert bare.returncode != 0 and "GPU(s) visible" in bare.stderr and "{" not in bare.stdout
+    lone = subprocess.run(cmd, cwd=root, env=dict(base, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True,
+                          text=True, timeout=120)
+    assert lone.returncode != 0 and "WORLD_SIZE=1" in lone.stderr and "{" not in lone.stdout

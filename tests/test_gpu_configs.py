@@ -148,8 +148,8 @@ def test_partial_decryptions_match_the_oracle(oracle, tfhe_amd, ring_name):
 
 
 def test_decrypt_batches_longer_than_one_grid_dimension(oracle, tfhe_amd):
-    """70 000 entries in one decrypt / partial-decrypt call (a grid dimension holds 65 535): raw row dots of
-    sampled entries, the last ones included, against the oracle."""
+    """70 000 entries in one decrypt / partial-decrypt / digest call (a grid dimension holds 65 535): raw row dots
+    and digests of sampled entries, the last ones included, against the oracle."""
     from tfhe_amd import _lib
 
     L = _lib.lib()
@@ -173,6 +173,14 @@ def test_decrypt_batches_longer_than_one_grid_dimension(oracle, tfhe_amd):
         cc[ring_o.ell - 1] = row[:n + 1]
         expect = og.row_dot_s(osk, cc, ring_o.ell - 1)
         assert int(raw[b]) == expect and int(bits[b]) == ring_o.is_zero_one(expect), b
+    # the digests of the same 70 000 entries in one call, against the oracle's digest of sampled entries
+    dig = eng.alloc(8 * batch)
+    _lib.check(L.gsw_digest_batch(eng.handle, ct.ptr, ct.stride, eng.compact_elems, batch, dig.ptr))
+    got = dig.download(np.uint64, batch)
+    entry = np.empty(eng.compact_elems, dtype=np.uint32)
+    for b in (0, 65534, 65535, 65536, 69999):
+        _lib.check(L.gsw_memcpy_d2h(eng.handle, entry.ctypes.data, ct.entry_ptr(b), 4 * eng.compact_elems))
+        assert int(got[b]) == oracle.digest(entry), b
 
 
 def test_validate_compact_counts_what_breaks_the_invariants(tfhe_amd):

@@ -57,3 +57,37 @@ def test_engine_matches_golden(path):
         assert np.array_equal(gsw.bit_decomp_inv_matrix(g["mult_dense_flat"], quirk=False), g["mul_gadget"])
     if "mp_decrypt_dense" in g:
         assert gsw.mp_decrypt_batch(sk, ct).tolist() == g["mp_decrypt_dense"].tolist()
+
+
+def test_engine_on_the_reference_held_products():
+    """The matrix products written out in the reference's own test code (helper.rs:166-183, field.rs:97-122,
+    pow2_ring.rs:231-260; tests/golden/reference_held_products.json) through the C ABI: square cases through
+    gsw_mul_dense / gsw_nand_dense (the trait's mult / nand, gsw_impl.rs:104-123), matrix-vector cases through
+    gsw_matvec."""
+    import json
+
+    import tfhe_amd
+    from tfhe_amd import _lib
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_held_products.json")) as f:
+        cases = json.load(f)["cases"]
+    L = _lib.lib()
+    for case in cases:
+        ring = tfhe_amd.Fp() if case["ring"] == "fp" else tfhe_amd.Zpow2(int(case["ring"][1:]))
+        gsw = tfhe_amd.GSW(ring, 1, ring.ell)  # (n, m) play no part in these products
+        eng = gsw.engine
+        a = np.array(case["a"], dtype=np.uint32)
+        expect = np.array(case["expect"], dtype=np.uint32)
+        if case["op"] == "matmul":
+            b = np.array(case["b"], dtype=np.uint32)
+            assert np.array_equal(gsw.mult_dense(a, b), expect), case["cite"]
+            assert gsw.last_dense_path() == 0  # arbitrary entries: the plain dim^3 kernel
+            want = (np.eye(a.shape[0], dtype=np.int64) - expect.astype(np.int64)) % ring.q
+            assert np.array_equal(gsw.nand_dense(a, b), want.astype(np.uint32)), case["cite"]
+        else:
+            vec = np.array(case["b"], dtype=np.uint32)
+            rows, cols = a.shape
+            d_a, d_o = eng.alloc_u32(a.size), eng.alloc_u32(rows)
+            d_a.upload(a)
+            _lib.check(L.gsw_matvec(eng.handle, d_a.ptr, rows, cols, cols, vec.ctypes.data, d_o.ptr))
+            assert d_o.download(np.uint32, rows).tolist() == expect.tolist(), case["cite"]

@@ -525,6 +525,27 @@ def test_dense_ops_arbitrary_entries(oracle, tfhe_amd, ring_name):
     assert gsw.bit_decomp_inv_matrix(ones)[0, 0] == oracle.bit_decomp_inv_matrix(ring_o, ones)[0, 0]
 
 
+@pytest.mark.parametrize("ring_name", ["fp", "z8"])
+def test_dense_ops_with_the_use_flatten_feature(oracle, tfhe_amd, ring_name):
+    """The reference's non-default cargo feature use_flatten (Cargo.toml:16-17) as a switch of the host mirror: add,
+    mult_const, mult and nand then apply flatten_matrix to their result (gsw_impl.rs:91-92,99-100,108-109,120-121),
+    with the `== 1` quirk of bit_decomp_inv (helper.rs:31-35)."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    n = 2
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, use_flatten=True)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    dim = ring_o.big_n(n)
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 2, size=(dim, dim), dtype=np.uint64).astype(np.uint32)  # small entries: products hit 0, 1, 2, ..
+    b = rng.integers(0, 2, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
+    a[np.arange(dim), np.arange(dim)] += 1
+    flat = lambda x: oracle.flatten_matrix(ring_o, x)  # noqa: E731
+    _assert_equal(gsw.mult_dense(a, b), flat(og.mult(a, b)), "mult + flatten")
+    _assert_equal(gsw.nand_dense(a, b), flat(og.nand(a, b)), "nand + flatten")
+    _assert_equal(gsw.add_dense(a, b), flat(og.add(a, b)), "add + flatten")
+    _assert_equal(gsw.mult_const_dense(a, 3 % ring_o.q), flat(og.mult_const(a, 3 % ring_o.q)), "mult_const + flatten")
+
+
 @pytest.mark.parametrize("ring_name,n", [("fp", 10), ("z32", 7), ("z8", 9), ("fp", 40)])
 def test_dense_mult_of_reference_format_ciphertexts_runs_on_mfma(oracle, tfhe_amd, ring_name, n):
     """FheScheme::mult / nand (gsw_impl.rs:104-123) on the reference's own N x N ciphertexts,
@@ -764,10 +785,14 @@ def test_mul_gadget_edge_valued_right_operands(oracle, tfhe_amd, ring_name, n, w
     """Right operands made of the values where the signed-digit split changes branch (carries into the top digit,
     the elements of Fp taken as x - p, the words of Z/2^32 that wrap), against left operands of all ones, all
     zeros and random words, so that the limb sums reach both ends of their range; with the 32-bit recombination
-    and, forced, with the 64-bit one."""
+    and, forced, with the 64-bit one (the context reports which one its last launch took); mult, nand and the
+    fused digest."""
+    from tfhe_amd import _lib
+
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
     gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=1)
     og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    eng = gsw.engine
     rng = np.random.default_rng(300 + n)
     edges = np.array([v for v in (_EDGE_FP if ring_name == "fp" else _EDGE_Z32) if v < ring_o.q], dtype=np.uint32)
     c1, c2 = _rand_compact(rng, ring_o, n, 4), _rand_compact(rng, ring_o, n, 4)
@@ -777,47 +802,81 @@ def test_mul_gadget_edge_valued_right_operands(oracle, tfhe_amd, ring_name, n, w
     c1[1] = ring_o.q - 1 if ring_name != "fp" else 0x7FFFFFFE  # p - 1: every bit but the lowest
     c1[2] = 0
     c1[3, ::2] = ring_o.q - 1
+    assert gsw.last_combine() == -1
     if wide:
         os.environ["GSW_FORCE_WIDE_COMBINE"] = "1"
     try:
-        d1 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c1)
-        d2 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)
+        d1 = tfhe_amd.Ciphertext.from_compact(eng, c1)
+        d2 = tfhe_amd.Ciphertext.from_compact(eng, c2)
         got = gsw.mult(d1, d2).to_compact()
+        assert gsw.last_combine() == (0 if wide else 1)
         got_nand = gsw.nand(d1, d2).to_compact()
+        assert gsw.last_combine() == (0 if wide else 1)
+        out, dig = tfhe_amd.Ciphertext(eng, 4), eng.alloc(8 * 4)
+        _lib.check(_lib.lib().gsw_mul_gadget_batch_digest(eng.handle, d1.ptr, d1.stride, d2.ptr, d2.stride, out.ptr,
+                                                          out.stride, 4, _lib.FLAG_NAND, dig.ptr))
+        assert gsw.last_combine() == (0 if wide else 1)
+        raw = out.buf.download(np.uint32, eng.compact_elems * 4).reshape(4, -1)
     finally:
         os.environ.pop("GSW_FORCE_WIDE_COMBINE", None)
+    assert dig.download(np.uint64, 4).tolist() == [oracle.digest(raw[b]) for b in range(4)]
+    _assert_equal(out.to_compact(), got_nand, "nand with the fused digest vs nand")
     for b in range(4):
         _assert_equal(got[b], og.mul_gadget(c1[b], c2[b]), f"mult[{b}] {ring_name} n={n} wide={wide}")
         _assert_equal(got_nand[b], og.mul_gadget(c1[b], c2[b], flags=oracle.FLAG_NAND), f"nand[{b}] {ring_name} n={n}")
 
 
-def test_n256_rows_with_the_64_bit_recombination(oracle, tfhe_amd):
+@pytest.mark.parametrize("ring_name", ["fp", "z32", "z30"])
+def test_n256_rows_with_the_64_bit_recombination(oracle, tfhe_amd, ring_name):
     """The fallback for contractions too long for the 32-bit recombination (more than about 32 000 K slots), forced
-    at n = 256 where interior tiles exist: sampled rows of one product against the oracle."""
-    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    at n = 256 where interior tiles exist (they take the general epilogue then): the context reports the 64-bit form
+    for the forced launches and the 32-bit one otherwise; mult, nand and the fused digest of whole products are
+    compared between the two forms, sampled rows with the oracle, the digests with the oracle's."""
+    from tfhe_amd import _lib
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
     n = 256
-    gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
-    og = oracle.GSW(ring_o, n, n * 31)
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=1)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    eng, L = gsw.engine, _lib.lib()
     rng = np.random.default_rng(77)
     c1, c2 = _rand_compact(rng, ring_o, n), _rand_compact(rng, ring_o, n)
+    c1[7] = ring_o.q - 1  # a row of (almost) all ones: the largest limb sums
+    d1, d2 = tfhe_amd.Ciphertext.from_compact(eng, c1), tfhe_amd.Ciphertext.from_compact(eng, c2)
+
+    def products():
+        mult = gsw.mult(d1, d2).to_compact()
+        first = gsw.last_combine()
+        out, dig = tfhe_amd.Ciphertext(eng, 1), eng.alloc(8)
+        _lib.check(L.gsw_mul_gadget_batch_digest(eng.handle, d1.ptr, d1.stride, d2.ptr, d2.stride, out.ptr, out.stride,
+                                                 1, _lib.FLAG_NAND, dig.ptr))
+        assert gsw.last_combine() == first
+        raw = out.buf.download(np.uint32, eng.compact_elems)
+        assert int(dig.download(np.uint64, 1)[0]) == oracle.digest(raw)
+        return first, mult, out.to_compact()
+
     os.environ["GSW_FORCE_WIDE_COMBINE"] = "1"
     try:
-        wide = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1),
-                        tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+        form, wide, wide_nand = products()
     finally:
         os.environ.pop("GSW_FORCE_WIDE_COMBINE", None)
-    lean = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1),
-                    tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    assert form == 0, "GSW_FORCE_WIDE_COMBINE=1 did not reach the kernel"
+    form, lean, lean_nand = products()
+    assert form == 1
     _assert_equal(wide, lean, "64-bit vs 32-bit recombination, whole product")
-    rows = np.concatenate([np.arange(0, 4), rng.integers(0, ring_o.big_n(n), 24), np.arange(ring_o.big_n(n) - 4, ring_o.big_n(n))])
+    _assert_equal(wide_nand, lean_nand, "64-bit vs 32-bit recombination, whole nand")
+    big_n = ring_o.big_n(n)
+    rows = np.concatenate([np.arange(0, 4), [7], rng.integers(0, big_n, 24), np.arange(big_n - 4, big_n)])
     for r in rows:
         _assert_equal(wide[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")
+        _assert_equal(wide_nand[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1, flags=oracle.FLAG_NAND), f"nand row {r} vs oracle")
 
 
 def test_n1024_takes_the_64_bit_recombination_natively(oracle, tfhe_amd):
     """n = 1024: 32 896 K slots, beyond the bound of the 32-bit recombination, so the contraction takes start values
     below 2^28 and the 64-bit form by itself; the shape also has a one-column (narrow) tail tile, a thin last row tile
-    and a half last stage.  Sampled rows of one product against the oracle."""
+    and a half last stage.  Sampled rows of one product and of one nand against the oracle; the fused digest against
+    the oracle's digest of the stored result."""
     import ctypes as C
     from tfhe_amd import _lib
 
@@ -828,11 +887,21 @@ def test_n1024_takes_the_64_bit_recombination_natively(oracle, tfhe_amd):
     assert lean.value == 0
     gsw = tfhe_amd.GSW(ring_d, n, n * 31, seed=1)
     og = oracle.GSW(ring_o, n, n * 31)
+    eng = gsw.engine
     rng = np.random.default_rng(1024)
     c1, c2 = _rand_compact(rng, ring_o, n), _rand_compact(rng, ring_o, n)
     c1[5] = P - 1  # a row of (almost) all ones: the largest limb sums
-    got = gsw.mult(tfhe_amd.Ciphertext.from_compact(gsw.engine, c1), tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)).to_compact()
+    d1, d2 = tfhe_amd.Ciphertext.from_compact(eng, c1), tfhe_amd.Ciphertext.from_compact(eng, c2)
+    got = gsw.mult(d1, d2).to_compact()
+    assert gsw.last_combine() == 0
+    out, dig = tfhe_amd.Ciphertext(eng, 1), eng.alloc(8)
+    _lib.check(_lib.lib().gsw_mul_gadget_batch_digest(eng.handle, d1.ptr, d1.stride, d2.ptr, d2.stride, out.ptr,
+                                                      out.stride, 1, _lib.FLAG_NAND, dig.ptr))
+    assert gsw.last_combine() == 0
+    assert int(dig.download(np.uint64, 1)[0]) == oracle.digest(out.buf.download(np.uint32, eng.compact_elems))
+    got_nand = out.to_compact()
     big_n = ring_o.big_n(n)
     rows = np.concatenate([np.arange(0, 8), rng.integers(0, big_n, 16), np.arange(big_n - 40, big_n, 5)])
     for r in rows:
         _assert_equal(got[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")
+        _assert_equal(got_nand[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1, flags=oracle.FLAG_NAND), f"nand row {r} vs oracle")

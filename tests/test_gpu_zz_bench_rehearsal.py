@@ -44,6 +44,30 @@ def test_two_rank_rehearsal_prints_one_contract_line(workload_args, expect_confi
 
 
 @pytest.mark.gpu
+def test_bare_gpus_2_makes_two_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (rehearsal mode: both on GPU 0
+    over gloo) and the line says how many ranks the process group saw."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSW_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "fp_n10", "--batch", "64"]
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["world_size_seen"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["config"]["exchange_verified"] is True
+    # without the rehearsal switch a one-GPU box has too few devices: refused, non-zero, nothing printed as a result
+    env.pop("GSW_BENCH_REHEARSAL")
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert proc.returncode != 0 and "GPU(s) visible" in proc.stderr
+        assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_result_drain_on_the_gpu_without_peers():
     """The device side of dist.ResultDrain (receive buffers, side stream, pinned host memory) with one rank."""
     import torch

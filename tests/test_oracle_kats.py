@@ -59,6 +59,41 @@ def test_z8_nalgebra(oracle):
     assert (oracle.matmul(z8, a, ident) == a).all()  # :253-261
 
 
+# ---- every matrix product the reference's own test code writes out (tests/golden/reference_held_products.json) ----
+def _reference_held_cases():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_held_products.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_mult_on_the_reference_held_products(oracle):
+    """The only pins of the operation `mult` is (`ciphertext1 * cipertext2`, gsw_impl.rs:107) that the reference's own
+    files hold: helper.rs:166-183 ([[1,2],[3,4]] * [[5,6],[7,8]] = [[19,22],[43,50]] over Fp, commented out there),
+    field.rs:97-122 and pow2_ring.rs:231-260.  Through the oracle's matmul, through its `mult` (square cases) and
+    through the independent big-integer restatement."""
+    from oracle import pyref
+
+    for case in _reference_held_cases():
+        r = oracle.fp() if case["ring"] == "fp" else oracle.zpow2(int(case["ring"][1:]))
+        pr = pyref.Ring("fp") if case["ring"] == "fp" else pyref.Ring("zpow2", int(case["ring"][1:]))
+        a = np.array(case["a"], dtype=np.uint32)
+        b = np.array(case["b"], dtype=np.uint32)
+        expect = np.array(case["expect"], dtype=np.uint32)
+        if case["op"] == "matvec":
+            b, expect = b.reshape(-1, 1), expect.reshape(-1, 1)
+        assert np.array_equal(oracle.matmul(r, a, b), expect), case["cite"]
+        assert np.array_equal(np.array(pyref.matmul(pr, a.tolist(), b.tolist()), dtype=np.uint32), expect), case["cite"]
+        if case["op"] == "matmul":
+            dim = a.shape[0]
+            gsw = oracle.GSW(r, 1, r.ell)  # (n, m) play no part in mult: any square matrices of one size
+            assert np.array_equal(gsw.mult(a, b), expect), case["cite"]
+            # nand = I - C1 C2 (gsw_impl.rs:114-123) follows from the same product
+            want = (np.eye(dim, dtype=np.int64) - expect.astype(np.int64)) % r.q
+            assert np.array_equal(gsw.nand(a, b), want.astype(np.uint32)), case["cite"]
+
+
 # ---- gsw/helper.rs:105-164 ----------------------------------------------------------
 def test_bit_decomp_and_inv(oracle):  # helper.rs:121-144
     r = oracle.fp()

@@ -78,9 +78,10 @@ def test_same_context_second_call_smaller_and_broadcast(oracle, tfhe_amd):
     assert np.array_equal(products[3], og.mul_gadget(c1[3], c2[0]))
 
 
-def test_chunks_through_the_array_at_n256_and_no_allocation(tfhe_amd):
+def test_chunks_through_the_array_at_n256_and_no_allocation(oracle, tfhe_amd):
     """n = 256: one prepared operand is 8.8 MB, so 9 products go through the 64 MiB array in two chunks; then
-    2 products.  Device memory in use does not change across the calls."""
+    2 products.  Device memory in use does not change across the calls; sampled rows of products of both chunks
+    are also checked against the oracle."""
     import torch
 
     from tfhe_amd import _lib
@@ -109,6 +110,46 @@ def test_chunks_through_the_array_at_n256_and_no_allocation(tfhe_amd):
         a = ref.buf.download(np.uint32, batch * ct)
         b = got.buf.download(np.uint32, batch * ct)
         assert np.array_equal(a, b), batch
+        og = oracle.GSW(oracle.fp(), 256, 256 * 31)
+        prod = b.reshape(batch, eng.big_n, eng.ld)
+        for e in (0, batch - 1):  # the first chunk and the last
+            c1, c2 = raw[first + e, :, :257], raw[9 + first + e, :, :257]
+            for r in (0, 30, 4097, eng.big_n - 1):
+                assert np.array_equal(prod[e, r:r + 1, :257], og.mul_gadget_rows(c1, c2, r, 1)), (batch, e, r)
+
+
+def test_two_contexts_share_the_array_without_racing(tfhe_amd):
+    """Two contexts (two streams) on one GPU call the entry point back to back with no synchronisation in between:
+    A (two chunks), B (two chunks), A again (one chunk).  The library queues the calls on the shared array, so each
+    result equals the allocating entry point's on the same operands."""
+    from tfhe_amd import _lib
+
+    L = _lib.lib()
+    ga = tfhe_amd.GSW(tfhe_amd.Fp(), 256, 256 * 31, seed=1)
+    gb = tfhe_amd.GSW(tfhe_amd.Fp(), 256, 256 * 31, seed=2)
+    ea, eb = ga.engine, gb.engine
+    ct = ea.compact_elems
+    pool = tfhe_amd.Ciphertext(ea, 36)
+    _lib.check(L.gsw_fill_uniform(ea.handle, 11, 1, 0, 2147483646, 0, pool.ptr, 36 * ct))
+    raw = pool.buf.download(np.uint32, 36 * ct).reshape(36, ea.big_n, ea.ld)
+    raw[:, :, 257:] = 0
+    pool.buf.upload(raw)
+    del raw
+    ref_a, ref_b, ref_a2 = (tfhe_amd.Ciphertext(ea, k) for k in (9, 9, 3))
+    got_a, got_b, got_a2 = (tfhe_amd.Ciphertext(ea, k) for k in (9, 9, 3))
+    calls = ((ea, 0, 9, ref_a, got_a), (eb, 18, 9, ref_b, got_b), (ea, 4, 3, ref_a2, got_a2))
+    for eng, first, batch, ref, _ in calls:
+        _lib.check(L.gsw_mul_gadget_batch(eng.handle, pool.entry_ptr(first), ct, pool.entry_ptr(first + 9), ct,
+                                          ref.ptr, ct, batch, 0))
+    ea.sync()
+    eb.sync()
+    for eng, first, batch, _, got in calls:  # no synchronisation between these three
+        _lib.check(L.gsw_mul_gadget_batch_static(eng.handle, pool.entry_ptr(first), ct, pool.entry_ptr(first + 9), ct,
+                                                 got.ptr, ct, batch, 0))
+    ea.sync()
+    eb.sync()
+    for _, _, batch, ref, got in calls:
+        assert np.array_equal(ref.buf.download(np.uint32, batch * ct), got.buf.download(np.uint32, batch * ct)), batch
 
 
 def test_sizes_beyond_the_array_are_refused(tfhe_amd):

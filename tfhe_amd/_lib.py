@@ -72,6 +72,7 @@ SIGNATURES = {
     "gsw_nand_dense": (_i, [_vp, _vp, _vp, _vp, _i]),
     "gsw_ctx_set_dense_fast": (_i, [_vp, _i]),
     "gsw_ctx_last_dense_path": (_i, [_vp]),
+    "gsw_ctx_last_combine": (_i, [_vp]),
     "gsw_validate_compact": (_i, [_vp, _vp, _sz, _i, C.POINTER(_u64)]),
     "gsw_prepare_rhs": (_i, [_vp, _vp, _sz, _vp, _i]),
     "gsw_mul_gadget_prepared": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _i, C.c_uint]),

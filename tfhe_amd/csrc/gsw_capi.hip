@@ -93,6 +93,11 @@ __device__ __align__(256) unsigned char g_static_scratch[GSW_STATIC_SCRATCH_BYTE
 constexpr int kMaxDevices = 64;
 std::mutex g_static_mutex;
 void *g_static_ptr[kMaxDevices];  // device address of g_static_scratch on each GPU, resolved on first use
+// Every context (and stream) of a GPU shares that GPU's array.  g_static_last[device] is recorded behind the last
+// contraction of every gsw_mul_gadget_batch_static call and waited for by the next call's stream before its first
+// preparation, so calls from different contexts queue up instead of overwriting each other's staged operands.
+// Created with the pointer above (at gsw_ctx_create): the entry point itself creates nothing.
+hipEvent_t g_static_last[kMaxDevices];
 
 // Device address of the scratch array on `device`, which must be the current device.  Called by
 // gsw_ctx_create, the library's set-up call on a device; resolved once per device.
@@ -103,6 +108,7 @@ int resolve_static_scratch(int device, void **out) {
         void *ptr = nullptr;
         HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_static_scratch)));
         if (!ptr) return fail(GSW_E_HIP, "hipGetSymbolAddress returned a null address for the static scratch array");
+        HIP_TRY(hipEventCreateWithFlags(&g_static_last[device], hipEventDisableTiming));
         g_static_ptr[device] = ptr;
     }
     *out = g_static_ptr[device];
@@ -133,6 +139,7 @@ struct gsw_ctx {
     uint64_t n_prepared, n_products;  // right operands prepared / products contracted since creation
     int dense_fast;        // MFMA path of gsw_mul_dense / gsw_nand_dense: 0 never, 1 from 1024 rows up, 2 whenever the form fits
     int last_dense_path;   // 0 = plain dim^3 kernel, 1 = MFMA contraction (what the last dense product used)
+    int last_combine;      // recombination of the last contraction launch: 1 = 32-bit, 0 = 64-bit on every tile, -1 = none yet
     void *static_scratch;  // this GPU's copy of the library's static scratch array (gsw_mul_gadget_batch_static)
     bool in_static_call;   // inside gsw_mul_gadget_batch_static: nothing may allocate, not even timing events
     void *small;         // scratch of the helpers that return values to the host (row dots, tables, staging)
@@ -259,7 +266,7 @@ int run_gemm(gsw_ctx *ctx, const gswk::GemmArgs &args) {
     a.pass_rows = ctx->pass_rows;
     a.pass_cols = ctx->pass_cols;
     ScopedTimer timer(ctx, 0, ctx->stream);
-    HIP_TRY(gswk::launch_gemm(ctx->ring, a, ctx->gemm_variant, ctx->stream));
+    HIP_TRY(gswk::launch_gemm(ctx->ring, a, ctx->gemm_variant, ctx->stream, &ctx->last_combine));
     return GSW_OK;
 }
 
@@ -375,6 +382,7 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
     }
     ctx->stream = ctx->own_stream;
     ctx->dense_fast = 1;
+    ctx->last_combine = -1;
     ctx->overlap_chunk = 128;
     // placement passes (row tiles x column tiles an XCD works on together): 8 x 8, and 16 x 4 once a product has
     // a dozen column tiles (n = 512: a right-operand panel is 2.1 MB there, and taller passes re-read it half
@@ -818,6 +826,7 @@ int gsw_ctx_set_dense_fast(gsw_ctx *ctx, int enable) {
 }
 
 int gsw_ctx_last_dense_path(const gsw_ctx *ctx) { return ctx ? ctx->last_dense_path : -1; }
+int gsw_ctx_last_combine(const gsw_ctx *ctx) { return ctx ? ctx->last_combine : -1; }
 
 // ---- the hot path ----
 
@@ -1067,21 +1076,33 @@ int gsw_mul_gadget_batch_static(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stri
         ~Guard() { c->in_static_call = false; }
     } guard(ctx);
     void *scratch = ctx->static_scratch;  // the device address, never the array's name
-    if (stride2 == 0) {
-        // one right operand for the whole batch: prepared once
-        if (int rc = prepare_rhs_on(ctx, d_c2c, 0, scratch, 1, ctx->stream)) return rc;
-        return mul_prepared(ctx, d_c1c, stride1, scratch, 0, d_out, stride_out, batch, flags, nullptr);
-    }
-    size_t chunk = GSW_STATIC_SCRATCH_BYTES / prep;
-    if (chunk > (size_t)batch) chunk = (size_t)batch;
-    for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
-        const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
-        if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, scratch, cur, ctx->stream)) return rc;
-        if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, scratch, prep, d_out + b0 * stride_out,
-                                  stride_out, cur, flags, nullptr))
-            return rc;
-    }
-    return GSW_OK;
+    // One user of the array at a time, in the order of the calls: the lock covers this call's enqueues, the event
+    // makes this stream wait for the previous call's last contraction (a no-op on the stream that recorded it).
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    hipEvent_t last = g_static_last[ctx->device];
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, last, 0));
+    auto body = [&]() -> int {
+        if (stride2 == 0) {
+            // one right operand for the whole batch: prepared once
+            if (int rc = prepare_rhs_on(ctx, d_c2c, 0, scratch, 1, ctx->stream)) return rc;
+            return mul_prepared(ctx, d_c1c, stride1, scratch, 0, d_out, stride_out, batch, flags, nullptr);
+        }
+        size_t chunk = GSW_STATIC_SCRATCH_BYTES / prep;
+        if (chunk > (size_t)batch) chunk = (size_t)batch;
+        for (size_t b0 = 0; b0 < (size_t)batch; b0 += chunk) {
+            const int cur = (int)((size_t)batch - b0 < chunk ? (size_t)batch - b0 : chunk);
+            if (int rc = prepare_rhs_on(ctx, d_c2c + b0 * stride2, stride2, scratch, cur, ctx->stream)) return rc;
+            if (int rc = mul_prepared(ctx, d_c1c + b0 * stride1, stride1, scratch, prep, d_out + b0 * stride_out,
+                                      stride_out, cur, flags, nullptr))
+                return rc;
+        }
+        return GSW_OK;
+    };
+    const int rc = body();
+    // also after a failure: whatever was enqueued still reads or writes the array
+    const hipError_t e = hipEventRecord(last, ctx->stream);
+    if (rc == GSW_OK && e != hipSuccess) return fail(GSW_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 // ---- gate lists over a pool of resident ciphertexts ----

@@ -58,7 +58,8 @@ struct GemmArgs {
     // Filled in by launch_gemm.  The accumulators of limb l start at acc_init[l] instead of 0: the right operand's
     // limbs are signed digits, so a limb sum may be negative, and for Fp the start values (chosen so that
     // sum_l 2^(8 l) acc_init[l] = 0 mod p) keep every sum non-negative without changing the result.  lean_combine:
-    // the sums stay below the bound of the 32-bit recombination (combine_limbs_lean).
+    // the sums stay below the bound of the 32-bit recombination (combine_limbs_lean) and interior tiles may take the
+    // branch-free epilogue; 0 sends every tile through the general epilogue (64-bit recombination).
     uint32_t acc_init[4];
     int lean_combine;
 };
@@ -109,7 +110,9 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
 //          4 = pipelined 16x16x64 MFMA, 256-row tile; 5 = same, 512-row tile;
 //          6 = 16x16x64 with 64-byte left-operand loads, 256-row tile; 7 = same, 512-row tile.
 // The prepared right operand must have been built for the variant's fragment order.
-hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream);
+// *lean_used (optional) receives GemmArgs::lean_combine as the launched kernel got it: 1 = 32-bit recombination,
+// 0 = the general epilogue with the 64-bit one on every tile.
+hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream, int *lean_used = nullptr);
 // The accumulator start values launch_gemm uses for a contraction over k_slots K slots (GemmArgs::acc_init) and
 // whether the 32-bit recombination applies (host only; `wide` asks for the 64-bit one).  False: no values exist.
 bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (&c)[4], int *lean);

@@ -512,7 +512,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
         // wave-uniform: are this wave's rows and the tile's columns all inside, away from the gadget's non-zeros?
         const int first_row = c.mt * tile_rows + c.wave * (16 * RG), first_col = c.nt * kTileCols;
         bool lean = first_row + 16 * RG <= p.rows && first_col + kTileCols <= p.out_cols &&
-                    (RING != kRingFp || p.lean_combine) && (unsigned long long)p.rows * (unsigned)p.ld_out < (1ull << 30);
+                    p.lean_combine && (unsigned long long)p.rows * (unsigned)p.ld_out < (1ull << 30);
         if (lean && p.mode != kModeMul) {
             const int j_lo = first_row / c.ell, j_hi = (first_row + 16 * RG - 1) / c.ell;
             lean = j_hi < first_col || j_lo >= first_col + kTileCols;
@@ -1199,6 +1199,7 @@ bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (
         // hover around 0 change sign all the time and every change flips the upper bits of the accumulator: start
         // values that vanish mod 2^32 (2^24 + 2^8 (2^24 - 2^16) = 2^32) keep them positive, 1.5 % faster at n = 512
         c[0] = 1u << 24, c[1] = (1u << 24) - (1u << 16), c[2] = 1u << 24, c[3] = 1u << 24;
+        if (wide) *lean = 0;  // every tile through the general epilogue (64-bit sum, then the mask)
         return true;
     }
     if (!wide && fp_acc_init(k_slots, (long)kLeanLimbMax, c)) return true;
@@ -1206,7 +1207,7 @@ bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (
     return fp_acc_init(k_slots, 1L << 28, c);
 }
 
-hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, hipStream_t stream) {
+hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, hipStream_t stream, int *lean_used) {
     if (args.batch <= 0) return hipSuccess;
     GemmArgs a = args;
     {
@@ -1235,27 +1236,6 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
         if ((m & 4) && a.e4 > kStageElems) a.e4 -= kStageElems;  // the prepared operand keeps its stride: wrong data, same work per stage
     }
 #endif
-    a.acc_init[0] = a.acc_init[1] = a.acc_init[2] = a.acc_init[3] = 0u;
-    a.lean_combine = 1;
-    if (ring.kind == kRingFp) {
-        // every left-operand word carries at most 32 ones; K slots past the right operand meet the digit 0
-        thread_local long cached_slots = -1;
-        thread_local uint32_t cached_init[4];
-        thread_local int cached_lean;
-        const long k_slots = 32L * a.e4;
-        if (k_slots != cached_slots) {
-            cached_lean = fp_acc_init(k_slots, (long)kLeanLimbMax, cached_init) ? 1 : 0;
-            if (!cached_lean && !fp_acc_init(k_slots, 1L << 28, cached_init)) return hipErrorInvalidValue;
-            cached_slots = k_slots;
-        }
-        for (int l = 0; l < 4; ++l) a.acc_init[l] = cached_init[l];
-        a.lean_combine = cached_lean;
-    } else {
-        // Z/2^M needs no start values (a sum read as uint32 is right mod 2^32 whatever its sign), but sums that
-        // hover around 0 change sign all the time and every change flips the upper bits of the accumulator: start
-        // values that vanish mod 2^32 (2^24 + 2^8 (2^24 - 2^16) = 2^32) keep them positive, 1.5 % faster at n = 512
-        a.acc_init[0] = 1u << 24, a.acc_init[1] = (1u << 24) - (1u << 16), a.acc_init[2] = 1u << 24, a.acc_init[3] = 1u << 24;
-    }
 #ifdef GSW_DIAGNOSTIC_BUILDS
     if (variant >= 10 && variant < 138 && ring.kind == kRingFp) {
         // diagnostic builds: variant = 10 + ABL
@@ -1300,6 +1280,7 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
     }
 #endif
     if (variant < 0 || variant > 9) return hipErrorInvalidValue;
+    if (lean_used) *lean_used = a.lean_combine;  // what the kernel launched below is told
 #ifndef GSW_DIAGNOSTIC_BUILDS
     if (variant != 2 && variant != 3 && variant != 9) return hipErrorInvalidValue;  // not in the shipped library
 #endif
@@ -2040,8 +2021,15 @@ hipError_t launch_digest(const uint32_t *x, size_t stride, size_t count, int bat
     unsigned gx = (unsigned)((count + 256 * 16 - 1) / (256 * 16));
     if (gx > 64) gx = 64;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(digest_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, stream, x, stride, count, digests);
-    return hipGetLastError();
+    // the batch rides in gridDim.y, which holds at most 65535: longer batches go in slabs
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int cur = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(digest_kernel, dim3(gx, (unsigned)cur), dim3(256), 0, stream, x + (size_t)b0 * stride, stride,
+                           count, digests + b0);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace gswk

@@ -41,6 +41,15 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def world_size_seen() -> int:
+    """The process group's own count of ranks (1 without a group): what actually took part, whatever was asked for."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def backend_name() -> str:
+    return dist.get_backend() if dist.is_initialized() else "none (single process)"
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -250,10 +250,13 @@ class GSW:
     (the reference uses the OS-seeded thread rng; its streams cannot be reproduced).
     `check_max=False` lifts the reference's `assert!(max <= P)` (error_sampling.rs:21), without
     which `keygen` over Zpow2<32> cannot run.
+    `use_flatten=True` stands for the reference's non-default cargo feature of that name (Cargo.toml:16-17): the dense
+    operations then apply flatten_matrix to their result (gsw_impl.rs:91-92,99-100,108-109,120-121).
     """
 
     def __init__(self, ring: Ring, n: int, m: int, sampler="gaussian", seed: int = 0, device: int = 0,
-                 check_max: bool = True):
+                 check_max: bool = True, use_flatten: bool = False):
+        self.use_flatten = bool(use_flatten)
         self.ring, self.n, self.m = ring, int(n), int(m)
         self.sampler, self.seed, self.check_max = sampler, int(seed), check_max
         self.engine = Engine(ring, n, m, device)
@@ -582,6 +585,8 @@ class GSW:
         d_a.upload(a)
         d_b.upload(b)
         check(fn(eng.handle, d_a.ptr, d_b.ptr, d_o.ptr, dim))
+        if self.use_flatten:  # gsw_impl.rs:108-109,120-121
+            check(_lib.lib().gsw_flatten(eng.handle, d_o.ptr, dim, dim // eng.ell))
         return d_o.download(np.uint32, a.size).reshape(dim, dim)
 
     def set_dense_fast(self, mode) -> None:
@@ -592,6 +597,11 @@ class GSW:
     def last_dense_path(self) -> int:
         """Which kernel the last dense product used: 0 = the plain N^3 kernel, 1 = the MFMA contraction."""
         return int(_lib.lib().gsw_ctx_last_dense_path(self.engine.handle))
+
+    def last_combine(self) -> int:
+        """How the last contraction launch recombined its limb sums: 1 = 32-bit form (branch-free epilogue on interior
+        tiles), 0 = the general epilogue with the 64-bit form on every tile, -1 = no launch yet."""
+        return int(_lib.lib().gsw_ctx_last_combine(self.engine.handle))
 
     def mult_dense(self, c1, c2) -> np.ndarray:
         """src/gsw/gsw_impl.rs:104-111 (default features): the N x N x N product on the reference's own
@@ -614,6 +624,8 @@ class GSW:
         d_a.upload(a)
         d_b.upload(b)
         check(_lib.lib().gsw_add(eng.handle, d_a.ptr, d_b.ptr, d_a.ptr, a.size))
+        if self.use_flatten:  # gsw_impl.rs:91-92
+            check(_lib.lib().gsw_flatten(eng.handle, d_a.ptr, a.shape[0], a.shape[1] // eng.ell))
         return d_a.download(np.uint32, a.size).reshape(a.shape)
 
     def mult_const_dense(self, c, constant: int) -> np.ndarray:
@@ -622,6 +634,8 @@ class GSW:
         d_a = self.engine.alloc_u32(a.size)
         d_a.upload(a)
         check(_lib.lib().gsw_mult_const(self.engine.handle, d_a.ptr, int(constant), a.size))
+        if self.use_flatten:  # gsw_impl.rs:99-100
+            check(_lib.lib().gsw_flatten(self.engine.handle, d_a.ptr, a.shape[0], a.shape[1] // self.engine.ell))
         return d_a.download(np.uint32, a.size).reshape(a.shape)
 
     def decrypt_dense(self, sk: SecretKey, c) -> int:
