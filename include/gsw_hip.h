@@ -323,6 +323,12 @@ int gsw_diag_stream_read(gsw_ctx *ctx, const void *d_src, size_t src_bytes, size
  * for Z/2^M they vanish mod 2^32.  *lean_out: the sums stay small enough for the 32-bit recombination
  * (`wide` != 0 asks for the values of the 64-bit one).  `bits` is M for GSW_RING_ZPOW2 and ignored for Fp. */
 int gsw_diag_limb_start_values(int ring_kind, int bits, int k_slots, int wide, uint32_t *h_start4, int *lean_out);
+/* Test aid, host only.  Over Fp the default kernel keeps bit i of a left-operand byte in place (byte values 0 / 2^c
+ * instead of 0 / 1: a cheaper fragment) and the preparation scales the matching right-operand rows by 2^-c mod p.
+ * Returns the mode for a contraction over k_slots K slots: 0 = no scaling (always for Z/2^M), 1 = c in {0, 1}, 2 = c in
+ * {0..3}; -1 for a bad argument.  A limb sum then lies in [-128 u, 127 u] with u = k_slots * w / 32, w = 32 / 48 / 120 for
+ * modes 0 / 1 / 2, and gsw_diag_limb_start_values returns the start values for that bound. */
+int gsw_diag_bit_scale_mode(int ring_kind, int bits, int k_slots);
 
 #ifdef __cplusplus
 }

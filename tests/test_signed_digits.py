@@ -23,19 +23,40 @@ def _start_values(ring_kind, bits, k_slots, wide):
     return rc, [int(v) for v in out], lean.value
 
 
+SCALE_WEIGHT = {0: 32, 1: 48, 2: 120}  # sum of the byte values 2^c over the 32 K slots of a word, per scaling mode
+
+
 @pytest.mark.parametrize("k_slots", [128, 384, 8320, 16512, 16544, 32000, 32768, 65536, 1 << 19, 1 << 20])
 @pytest.mark.parametrize("wide", [0, 1])
 def test_fp_start_values_vanish_mod_p_and_bound_the_sums(k_slots, wide):
+    from tfhe_amd import _lib
+
     rc, c, lean = _start_values(0, 31, k_slots, wide)
     assert rc == 0
     assert sum(v << (8 * l) for l, v in enumerate(c)) % P == 0
+    mode = _lib.lib().gsw_diag_bit_scale_mode(0, 31, k_slots)
+    assert mode in SCALE_WEIGHT
+    units = k_slots // 32 * SCALE_WEIGHT[mode]  # a limb sum lies in [-128 units, 127 units]
     top = LEAN_LIMB_MAX if lean else 1 << 28
     for v in c:
-        assert v - 128 * k_slots >= 0 and v + 127 * k_slots <= top
+        assert v - 128 * units >= 0 and v + 127 * units <= top
     if wide:
         assert lean == 0
     elif 255 * k_slots + 255 <= LEAN_LIMB_MAX:
         assert lean == 1  # every benchmark shape: n = 512 has 16 512 slots
+    # the benchmark shapes: n = 256 scales by 2^(k & 3), n = 512 by 2^(k & 1), and both keep the 32-bit recombination
+    assert _lib.lib().gsw_diag_bit_scale_mode(0, 31, 8320) == 2 and _lib.lib().gsw_diag_bit_scale_mode(0, 31, 16512) == 1
+    assert _lib.lib().gsw_diag_bit_scale_mode(1, 32, 8320) == 0
+
+
+def test_scaled_bits_identity():
+    """(2^c bit) * (2^-c x) = bit * x mod p, and 2^-c x mod p is the 31-bit rotation the preparation uses."""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([np.array(EDGES, np.uint64), rng.integers(0, P, 100000, dtype=np.uint64)])
+    for c in range(4):
+        rot = ((x >> np.uint64(c)) | (x << np.uint64(31 - c))) & np.uint64(P)
+        assert np.array_equal((rot << np.uint64(c)) % np.uint64(P), x % np.uint64(P))
+        assert rot.max() < P
 
 
 def test_zpow2_start_values_vanish_mod_2_32():

@@ -104,6 +104,7 @@ SIGNATURES = {
     "gsw_wire_read_compact": (_i, [_vp, _vp, _sz, _vp, _sz, _i, C.POINTER(_i)]),
     "gsw_diag_stream_read": (_i, [_vp, _vp, _sz, _sz, _i, _sz]),
     "gsw_diag_limb_start_values": (_i, [_i, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "gsw_diag_bit_scale_mode": (_i, [_i, _i, _i]),
     "gsw_digest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _vp]),
 }
 

@@ -157,6 +157,13 @@ struct gsw_ctx {
 
 namespace {
 
+// scaled bits go with the default kernel only (the cross-check kernels read unscaled digits)
+// (GSW_BIT_SCALE=0 in the environment turns them off for A/B timing and cross-checks)
+int scale_mode_for(const gsw_ctx *ctx, int e4) {
+    static const bool on = [] { const char *e = getenv("GSW_BIT_SCALE"); return !(e && e[0] == '0'); }();
+    return on && ctx->gemm_variant == 9 ? gswk::bit_scale_mode(ctx->ring, e4) : 0;
+}
+
 int use_device(const gsw_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     return GSW_OK;
@@ -775,6 +782,7 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
             pa.batch = 1;
             pa.packed_tail = packed_tail;
             pa.layout16 = 1;
+            pa.scale_mode = scale_mode_for(ctx, pa.e4);
             // The kernel places one batch entry per XCD at a time, so the single product is cut into slabs of
             // `slab` rows that play the part of batch entries sharing one right operand.  Slot lists with a
             // stride of one row let every entry start at any row: the last slab is moved up to end at row N
@@ -796,6 +804,7 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
             a.batch = entries;
             a.mode = gswk::kModeMul;
             a.packed_tail = packed_tail;
+            a.scale_mode = scale_mode_for(ctx, a.e4);
             a.lhs_slot = d_rows;
             a.out_slot = d_rows;
             if (int rc = run_gemm(ctx, a)) return rc;
@@ -849,6 +858,7 @@ static int prepare_rhs_on(gsw_ctx *ctx, const uint32_t *d_c2c, size_t stride_c2c
     a.batch = batch;
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
+    a.scale_mode = scale_mode_for(ctx, a.e4);
     a.src_slot = d_slots;
     a.dst_slot = d_dst_slots;
     return run_prepare(ctx, a, stream);
@@ -901,6 +911,7 @@ static int mul_prepared(gsw_ctx *ctx, const uint32_t *d_c1c, size_t stride1, con
     a.batch = batch;
     a.mode = (flags & GSW_FLAG_NAND) ? gswk::kModeNand : gswk::kModeMul;
     a.packed_tail = ctx->packed_tail;
+    a.scale_mode = scale_mode_for(ctx, a.e4);
     a.digests = (unsigned long long *)d_digests;
     a.lhs_slot = d_lhs_slots;
     a.out_slot = d_out_slots;
@@ -1336,6 +1347,7 @@ int gsw_prepare_pk(gsw_ctx *ctx, const uint32_t *h_pk_matrix, void *d_pk_prepare
     a.batch = 1;
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
+    a.scale_mode = scale_mode_for(ctx, a.e4);
     if (int rc = run_prepare(ctx, a, ctx->stream)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's host matrix is free again
     return GSW_OK;
@@ -1394,6 +1406,7 @@ int gsw_encrypt_batch(gsw_ctx *ctx, const void *d_pk_prepared, const uint32_t *d
     a.batch = batch;
     a.mode = gswk::kModeEncrypt;
     a.packed_tail = ctx->packed_tail;
+    a.scale_mode = scale_mode_for(ctx, a.e4);
     return run_gemm(ctx, a);
 }
 
@@ -1676,6 +1689,7 @@ int gsw_keygen_device(gsw_ctx *ctx, uint64_t seed, uint64_t first_stream, int sa
     a.batch = 1;
     a.packed_tail = ctx->packed_tail;
     a.layout16 = ctx->gemm_variant >= 4;
+    a.scale_mode = scale_mode_for(ctx, a.e4);
     if (int rc = run_prepare(ctx, a, st)) return rc;
     if (d_pk_matrix_out)
         HIP_TRY(hipMemcpyAsync(d_pk_matrix_out, d_pk, m * ctx->ld * 4, hipMemcpyDeviceToDevice, st));
@@ -1705,10 +1719,32 @@ int gsw_diag_limb_start_values(int ring_kind, int bits, int k_slots, int wide, u
     ring.ell = ring_kind == GSW_RING_FP_M31 ? 31 : bits;
     ring.mask = ring_kind == GSW_RING_FP_M31 ? gswk::kFpP : (bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u);
     uint32_t c[4];
-    if (!gswk::limb_start_values(ring, k_slots, wide != 0, c, lean_out))
+    // what launch_gemm does for the default kernel: the scaling mode of the contraction's length, its sums' bound
+    const int e4 = (k_slots + 31) / 32;
+    const long units = gswk::scale_units(e4, gswk::bit_scale_mode(ring, e4));
+    if (!gswk::limb_start_values(ring, units, wide != 0, c, lean_out))
         return fail(GSW_E_INVALID, "no start values for %d K slots", k_slots);
     for (int l = 0; l < 4; ++l) h_start4[l] = c[l];
     return GSW_OK;
+}
+
+#ifdef GSW_EXP_TILE_CLOCK
+int gsw_diag_tile_clock(gsw_ctx *ctx, uint64_t *h_out8, int reset) {
+    if (!ctx || !h_out8) return fail(GSW_E_INVALID, "bad argument");
+    if (int rc = use_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(gswk::read_tile_clock((unsigned long long *)h_out8, reset != 0));
+    return GSW_OK;
+}
+#endif
+
+int gsw_diag_bit_scale_mode(int ring_kind, int bits, int k_slots) {
+    if (k_slots <= 0 || (ring_kind != GSW_RING_FP_M31 && ring_kind != GSW_RING_ZPOW2)) return -1;
+    gswk::RingDesc ring;
+    ring.kind = ring_kind == GSW_RING_FP_M31 ? gswk::kRingFp : gswk::kRingZpow2;
+    ring.ell = ring_kind == GSW_RING_FP_M31 ? 31 : bits;
+    ring.mask = ring_kind == GSW_RING_FP_M31 ? gswk::kFpP : (bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u);
+    return gswk::bit_scale_mode(ring, (k_slots + 31) / 32);
 }
 
 int gsw_digest_batch(gsw_ctx *ctx, const uint32_t *d_x, size_t stride, size_t count, int batch, uint64_t *d_digests) {

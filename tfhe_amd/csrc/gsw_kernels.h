@@ -62,6 +62,11 @@ struct GemmArgs {
     // branch-free epilogue; 0 sends every tile through the general epilogue (64-bit recombination).
     uint32_t acc_init[4];
     int lean_combine;
+    // How the left fragments are made (see "Scaled bits" in gsw_kernels.hip): 0 = bytes in {0, 1}; Fp and the default
+    // kernel only: 1 / 2 = bit i of a byte kept in place (bytes in {0, 2^c}, c = i & 1 / i), the prepared right operand
+    // scaled by 2^-c to match.  Must be the mode the right operand was prepared with (bit_scale_mode of the ring
+    // and e4 when the default kernel runs, else 0).
+    int scale_mode;
 };
 
 inline int col_tiles(int out_cols) { return (out_cols + kTileCols - 1) / kTileCols; }
@@ -100,6 +105,7 @@ struct PrepArgs {
     int batch;
     int packed_tail;  // kTailNone / kTailPacked / kTailNarrow
     int layout16;  // fragment order of the 16x16x64 kernels (variants 4, 5) instead of the 32x32x32 ones
+    int scale_mode;  // rows scaled by 2^-c for the contraction's scaled bits (GemmArgs::scale_mode); layout16 only
     const uint32_t *src_slot;  // optional slot list (device, `batch` entries) into src; null means slot b
     const uint32_t *dst_slot;  // optional slot list into dst (a cache of prepared operands); null means slot b
 };
@@ -115,7 +121,16 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
 hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &a, int variant, hipStream_t stream, int *lean_used = nullptr);
 // The accumulator start values launch_gemm uses for a contraction over k_slots K slots (GemmArgs::acc_init) and
 // whether the 32-bit recombination applies (host only; `wide` asks for the 64-bit one).  False: no values exist.
+// (k_slots counts K slots whose left-operand byte is 0 or 1; with scaled bits pass scale_units(e4, mode))
 bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (&c)[4], int *lean);
+// The scaling of the left fragments' bits the default kernel uses for a contraction over e4 left-operand words
+// (0 for Z/2^M), and the bound of its limb sums in units of {0, 1} K slots.
+int bit_scale_mode(const RingDesc &ring, int e4);
+long scale_units(int e4, int mode);
+
+#ifdef GSW_EXP_TILE_CLOCK
+hipError_t read_tile_clock(unsigned long long *out8, bool reset);
+#endif
 
 // output formats of the gadget decomposition (GSW_DECOMP_* of the C header)
 constexpr int kDecompU32 = 0;   // one uint32 per bit: the reference's matrix of ring 0 / 1 values

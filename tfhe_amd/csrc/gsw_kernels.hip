@@ -90,6 +90,47 @@ __device__ __forceinline__ uint32_t signed_digits(uint32_t x) {
     return (x + 0x80808080u) ^ 0x80808080u;
 }
 
+// Scaled bits (Fp only).  The left fragments are cheaper to make when bit i of a byte stays where it is:
+// dword i of a fragment becomes y & (0x01010101 << i) -- bytes in {0, 2^i}, one instruction -- instead of
+// (y >> i) & 0x01010101 -- bytes in {0, 1}, two.  The right operand pays for it once, in its preparation: the row
+// that meets the K slot of bit k is multiplied by 2^-c, c = k & 3, before it is split into digits, so that
+// (2^c bit) (2^-c x) = bit x mod p.  In Fp = Z/(2^31 - 1) that product is a rotation of the 31-bit value by c
+// places to the right.  The limb sums grow with the weights (1 + 2 + 4 + 8) / 4, so mode 2 (c = k & 3) serves
+// contractions short enough for the 32-bit recombination with those sums, mode 1 (c = k & 1: dwords 0, 1 masked in
+// place, dwords 2, 3 after one shared shift) the longer ones, mode 0 (no scaling) Z/2^M, where 2 has no inverse.
+__device__ __forceinline__ uint32_t fp_scale_down(uint32_t x, int c) {
+    return ((x >> c) | (x << (31 - c))) & kFpP;  // x * 2^-c mod p for canonical x, 0 <= c < 31
+}
+
+template <int SCALE>
+__device__ __forceinline__ int scale_shift_of_bit(int bit) {
+    return SCALE == 2 ? (bit & 3) : SCALE == 1 ? (bit & 1) : 0;
+}
+
+// The int8 fragment (16 K slots of one row) from its word, already shifted to the lane's half: y = x >> 4 h.
+template <int SCALE>
+__device__ __forceinline__ v4i expand_bits(uint32_t y) {
+    v4i f;
+    if (SCALE == 2) {
+        f[0] = (int)(y & 0x01010101u);
+        f[1] = (int)(y & 0x02020202u);
+        f[2] = (int)(y & 0x04040404u);
+        f[3] = (int)(y & 0x08080808u);
+    } else if (SCALE == 1) {
+        const uint32_t y2 = y >> 2;
+        f[0] = (int)(y & 0x01010101u);
+        f[1] = (int)(y & 0x02020202u);
+        f[2] = (int)(y2 & 0x01010101u);
+        f[3] = (int)(y2 & 0x02020202u);
+    } else {
+        f[0] = (int)(y & 0x01010101u);
+        f[1] = (int)((y >> 1) & 0x01010101u);
+        f[2] = (int)((y >> 2) & 0x01010101u);
+        f[3] = (int)((y >> 3) & 0x01010101u);
+    }
+    return f;
+}
+
 // ------------------------------------------------------------------ right-operand preparation
 //
 // One workgroup per (K element e, column tile nt, batch entry): reads the 32 source rows
@@ -139,7 +180,7 @@ __global__ __launch_bounds__(256) void prepare_rhs_kernel(PrepArgs a, int ell) {
 // The same for the 16x16x64 kernels: one workgroup per (stage t, MFMA step p, column tile, batch
 // entry) builds the fragments [limb][column group] of that step from elements 4t + p (K groups 0, 1)
 // and 4t + 2 + p (K groups 2, 3).  Lane 16 g + c of a fragment: column c of the group, K group g.
-template <int RING>
+template <int RING, int SCALE>
 __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[8 * 256];
     const int tid = threadIdx.x;
@@ -159,7 +200,9 @@ __global__ __launch_bounds__(256) void prepare_rhs16_kernel(PrepArgs a, int ell)
                 const int bit = 4 * h + i + 8 * tt;
                 const int row = e * ell + bit;
                 if (bit < ell && row < a.rows_valid) {
-                    const uint32_t x = signed_digits<RING>(src[(size_t)row * a.ld_src + col]);
+                    uint32_t v = src[(size_t)row * a.ld_src + col];
+                    if (SCALE) v = fp_scale_down(v, scale_shift_of_bit<SCALE>(bit));  // see "Scaled bits"
+                    const uint32_t x = signed_digits<RING>(v);
 #pragma unroll
                     for (int l = 0; l < 4; ++l) limb[l] |= ((x >> (8 * l)) & 0xFFu) << (8 * tt);
                 }
@@ -199,9 +242,13 @@ hipError_t launch_prepare(const RingDesc &ring, const PrepArgs &a, hipStream_t s
     if (a.batch <= 0) return hipSuccess;
     if (a.layout16) {
         dim3 grid((unsigned)(a.e4 / 2), (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
-        if (ring.kind == kRingFp) hipLaunchKernelGGL(prepare_rhs16_kernel<kRingFp>, grid, dim3(256), 0, stream, a, ring.ell);
-        else hipLaunchKernelGGL(prepare_rhs16_kernel<kRingZpow2>, grid, dim3(256), 0, stream, a, ring.ell);
+        if (a.scale_mode < 0 || a.scale_mode > 2 || (a.scale_mode && ring.kind != kRingFp)) return hipErrorInvalidValue;
+        if (ring.kind != kRingFp) hipLaunchKernelGGL((prepare_rhs16_kernel<kRingZpow2, 0>), grid, dim3(256), 0, stream, a, ring.ell);
+        else if (a.scale_mode == 2) hipLaunchKernelGGL((prepare_rhs16_kernel<kRingFp, 2>), grid, dim3(256), 0, stream, a, ring.ell);
+        else if (a.scale_mode == 1) hipLaunchKernelGGL((prepare_rhs16_kernel<kRingFp, 1>), grid, dim3(256), 0, stream, a, ring.ell);
+        else hipLaunchKernelGGL((prepare_rhs16_kernel<kRingFp, 0>), grid, dim3(256), 0, stream, a, ring.ell);
     } else {
+        if (a.scale_mode) return hipErrorInvalidValue;  // the 32x32x32 kernels read unscaled digits
         dim3 grid((unsigned)a.e4, (unsigned)col_tiles(a.cols_valid), (unsigned)a.batch);
         if (ring.kind == kRingFp) hipLaunchKernelGGL(prepare_rhs_kernel<kRingFp>, grid, dim3(256), 0, stream, a, ring.ell);
         else hipLaunchKernelGGL(prepare_rhs_kernel<kRingZpow2>, grid, dim3(256), 0, stream, a, ring.ell);
@@ -645,7 +692,7 @@ constexpr int rowblock_lds_bytes() { return 2 * WAVES * 4096 + kPipeBuffers * kS
 
 // PACKED: kTailNone (full tile), kTailPacked (tail tile of 32 MFMA columns), kTailNarrow (of 16: its stages are
 // two fragments, 2 KiB apart in the prepared operand).
-template <int RING, int WAVES, int PACKED>
+template <int RING, int WAVES, int PACKED, int SCALE = 0>
 __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
                                                      int mt, unsigned char *smem) {
     constexpr int kRows = 64 * WAVES;
@@ -763,13 +810,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
                 const int f0 = grp * kGroup - step * kNB;
                 if (f0 == 0) {
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const uint32_t y = (step == 0 ? w[rg].x : w[rg].y) >> sh;
-                        fa[rg][0] = (int)(y & 0x01010101u);
-                        fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-                        fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-                        fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-                    }
+                    for (int rg = 0; rg < 4; ++rg) fa[rg] = expand_bits<SCALE>((step == 0 ? w[rg].x : w[rg].y) >> sh);
                 }
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) {
@@ -821,7 +862,7 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
 #define GSW_SKEW_INTERLEAVE 1
 #endif
 
-template <int RING>
+template <int RING, int SCALE>
 __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
                                                  unsigned char *smem) {
     constexpr int WAVES = 4;
@@ -895,13 +936,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     };
     auto expand = [&](v4i (&fa)[4], const uint32_t (&word)[4]) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const uint32_t y = word[rg] >> sh;
-            fa[rg][0] = (int)(y & 0x01010101u);
-            fa[rg][1] = (int)((y >> 1) & 0x01010101u);
-            fa[rg][2] = (int)((y >> 2) & 0x01010101u);
-            fa[rg][3] = (int)((y >> 3) & 0x01010101u);
-        }
+        for (int rg = 0; rg < 4; ++rg) fa[rg] = expand_bits<SCALE>(word[rg] >> sh);
     };
     auto read_frags = [&](v4i (&fb)[4], int buf, int grp) {
         const unsigned char *sb = smem + kLhsRing + buf * kRhsStage + lane * 16 + grp * 4 * kFragBytes;
@@ -1033,12 +1068,39 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     }
 }
 
-template <int RING>
+#ifdef GSW_EXP_TILE_CLOCK
+// diagnostic build: shader-clock cycles and count of the workgroups of each kind
+// (0 full tile, 1 last column tile, 2 last row tile, 3 both)
+__device__ unsigned long long g_tile_clock[8];
+hipError_t read_tile_clock(unsigned long long *out8, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tile_clock), 64);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tile_clock), z, 64);
+    }
+    return e;
+}
+#endif
+
+template <int RING, int SCALE>
 __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int ell, uint32_t mask, int nt_count,
                                                               int mt_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int b, nt, mt;
     if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
+#ifdef GSW_EXP_TILE_CLOCK
+    struct TileClock {
+        unsigned long long t0;
+        int kind;
+        __device__ TileClock(int k) : t0(__builtin_readcyclecounter()), kind(k) {}
+        __device__ ~TileClock() {
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_tile_clock[2 * kind], __builtin_readcyclecounter() - t0);
+                atomicAdd(&g_tile_clock[2 * kind + 1], 1ull);
+            }
+        }
+    } tile_clock((nt == nt_count - 1 ? 1 : 0) + (mt == mt_count - 1 ? 2 : 0));
+#endif
 #if defined(GSW_EXP_DEPHASE) || defined(GSW_EXP_PRIO)
     // experiments on the two workgroups that share a CU (ids 256 apart: 8 XCDs x 32 CUs are filled first)
     const bool second = (blockIdx.x >> 8) & 1;
@@ -1051,10 +1113,10 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     if (second) __builtin_amdgcn_s_setprio(GSW_EXP_PRIO);
 #endif
     if (p.packed_tail && nt == nt_count - 1) {
-        if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow>(p, ell, mask, b, nt, mt, smem);
-        else gemm16_rowblock_body<RING, 4, kTailPacked>(p, ell, mask, b, nt, mt, smem);
+        if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem);
+        else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem);
     } else {
-        gemm16_skew_body<RING>(p, ell, mask, b, nt, mt, smem);
+        gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem);
     }
 }
 
@@ -1170,8 +1232,8 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm_kernel(GemmArgs p, int el
 // below `top` (kLeanLimbMax for the 32-bit recombination, else 2^28 for the 64-bit one).  C_3 and C_2 are
 // stepped until the target -(2^16 C_2 + 2^24 C_3) mod p has a representative C_0 + 2^8 C_1 in range, which
 // covers every integer of [257 lo, 257 hi] once hi - lo >= 255.
-static bool fp_acc_init(long k_slots, long top, uint32_t (&c)[4]) {
-    const long lo = 128 * k_slots, hi = top - 127 * k_slots;
+static bool fp_acc_init(long units, long top, uint32_t (&c)[4]) {
+    const long lo = 128 * units, hi = top - 127 * units;
     if (hi - lo < 255) return false;
     const long P = (long)kFpP;
     const long span = hi - lo < 2048 ? hi - lo : 2048;
@@ -1190,6 +1252,19 @@ static bool fp_acc_init(long k_slots, long top, uint32_t (&c)[4]) {
         }
     }
     return false;
+}
+
+long scale_units(int e4, int mode) { return (long)e4 * (mode == 2 ? 120 : mode == 1 ? 48 : 32); }
+
+int bit_scale_mode(const RingDesc &ring, int e4) {
+    if (ring.kind != kRingFp) return 0;
+    // the widest scaling whose limb sums still fit the 32-bit recombination; failing that (very long
+    // contractions: the 64-bit one either way) the widest that fits its bound
+    for (int mode = 2; mode >= 0; --mode)
+        if (255 * scale_units(e4, mode) + 255 <= (long)kLeanLimbMax) return mode;
+    for (int mode = 2; mode >= 1; --mode)
+        if (255 * scale_units(e4, mode) + 255 <= (1L << 28)) return mode;
+    return 0;
 }
 
 bool limb_start_values(const RingDesc &ring, long k_slots, bool wide, uint32_t (&c)[4], int *lean) {
@@ -1216,7 +1291,9 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
         thread_local long cached_slots = -1;
         thread_local int cached_kind = -1, cached_wide = -1, cached_lean = 0;
         thread_local uint32_t cached_init[4];
-        const long k_slots = 32L * a.e4;
+        if (a.scale_mode < 0 || a.scale_mode > 2 || (a.scale_mode && (ring.kind != kRingFp || variant != 9))) return hipErrorInvalidValue;
+        // the limb sums' bound in units of one {0, 1} K slot (scaled bits weigh 2^c)
+        const long k_slots = scale_units(a.e4, a.scale_mode);
         const char *env = getenv("GSW_FORCE_WIDE_COMBINE");
         const int wide = env && env[0] == '1';
         if (k_slots != cached_slots || ring.kind != cached_kind || wide != cached_wide) {
@@ -1342,8 +1419,10 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
 #else
             constexpr int kSkewLds = rowblock_lds_bytes<4>();
 #endif
-            if (fp) GSW_LAUNCH((binlimb_gemm16_skew<kRingFp>), 256, kSkewLds);
-            else GSW_LAUNCH((binlimb_gemm16_skew<kRingZpow2>), 256, kSkewLds);
+            if (!fp) GSW_LAUNCH((binlimb_gemm16_skew<kRingZpow2, 0>), 256, kSkewLds);
+            else if (a.scale_mode == 2) GSW_LAUNCH((binlimb_gemm16_skew<kRingFp, 2>), 256, kSkewLds);
+            else if (a.scale_mode == 1) GSW_LAUNCH((binlimb_gemm16_skew<kRingFp, 1>), 256, kSkewLds);
+            else GSW_LAUNCH((binlimb_gemm16_skew<kRingFp, 0>), 256, kSkewLds);
             break;
         }
     }

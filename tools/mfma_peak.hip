@@ -30,6 +30,18 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const v4i *in, int *out, int
             a1[i] &= 0x01010101;
         }
     }
+    if (BINARY_A == 3) {  // bit i of a byte kept in place in fragment dword i: bytes in {0, 2^i}, i = 0..3
+        for (int i = 0; i < 4; ++i) {
+            a0[i] &= 0x01010101 << i;
+            a1[i] &= 0x01010101 << i;
+        }
+    }
+    if (BINARY_A == 4) {  // the same with i & 1: bytes in {0, 1} and {0, 2}
+        for (int i = 0; i < 4; ++i) {
+            a0[i] &= 0x01010101 << (i & 1);
+            a1[i] &= 0x01010101 << (i & 1);
+        }
+    }
     if (BINARY_A == 2) {  // the binary operand in the B position instead
         for (int l = 0; l < 4; ++l)
             for (int i = 0; i < 4; ++i) b[l][i] &= 0x01010101;
@@ -100,6 +112,9 @@ int main(int argc, char **argv) {
     run<32, 1>("32x32x32 i8, A bytes in {0,1}", d_in, d_out, iters, blocks);
     run<16, 0>("16x16x64 i8, random A and B", d_in, d_out, iters, blocks);
     run<16, 1>("16x16x64 i8, A bytes in {0,1}", d_in, d_out, iters, blocks);
+    run<16, 3>("16x16x64 i8, A bytes in {0,2^i}, i<4", d_in, d_out, iters, blocks);
+    run<16, 4>("16x16x64 i8, A bytes in {0,1},{0,2}", d_in, d_out, iters, blocks);
+    run<16, 1>("16x16x64 i8, A bytes in {0,1} again", d_in, d_out, iters, blocks);
     run<32, 2>("32x32x32 i8, B bytes in {0,1}", d_in, d_out, iters, blocks);
     run<16, 2>("16x16x64 i8, B bytes in {0,1}", d_in, d_out, iters, blocks);
     return 0;
