@@ -386,8 +386,8 @@ __device__ __forceinline__ bool map_workgroup(int batch, int nt_count, int mt_co
 // left-operand panel among 8 column tiles, so each byte crosses the fabric into that L2 about once
 // per pass instead of once per workgroup.  Speed only: results do not depend on placement.
 __device__ __forceinline__ bool map_workgroup_blocked(int batch, int nt_count, int mt_count, int kPassRows,
-                                                      int kPassCols, int &b, int &nt, int &mt) {
-    const int id = blockIdx.x;
+                                                      int kPassCols, int &b, int &nt, int &mt, int id = -1) {
+    if (id < 0) id = blockIdx.x;
     const int xcd = id & 7, local = id >> 3;
     const int per = mt_count * nt_count;
     b = (local / per) * 8 + xcd;
@@ -1120,6 +1120,48 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     }
 }
 
+#ifdef GSW_EXP_PERSIST
+// Experiment (GSW_PERSIST=1 on a -DGSW_EXP_PERSIST library): a persistent, pass-synchronised grid.  512 workgroups, two
+// per CU, stay resident; the 64 of an XCD walk that XCD's tile list (the order of map_workgroup_blocked) in rounds of
+// 64 consecutive tiles and meet at a counter before every round, so that the tiles that share operand panels
+// start together and stream them through the L2 in step.  The wait is bounded: a workgroup that does not see the
+// others arrive (slots held by another kernel) goes on alone after a while.
+__device__ unsigned g_persist_count[8];
+
+template <int RING, int SCALE>
+__global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_persistent(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                                         int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = ((p.batch + 7) / 8) * nt_count * mt_count;  // tiles in an XCD's list (some map to no entry)
+    const int rounds = (per_xcd + 63) / 64;
+    for (int r = 0; r < rounds; ++r) {
+        if (r > 0) {
+            __syncthreads();  // this workgroup is done with its tile of the round before (LDS included)
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_persist_count[xcd], 1u);
+                const unsigned target = 64u * (unsigned)r;
+                for (int spins = 0; spins < 4000; ++spins) {
+                    if (__hip_atomic_load(&g_persist_count[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+        }
+        int b, nt, mt;
+        const int local = r * 64 + slot;
+        if (local >= per_xcd || !map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt, local * 8 + xcd))
+            continue;
+        if (p.packed_tail && nt == nt_count - 1) {
+            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem);
+            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem);
+        } else {
+            gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem);
+        }
+    }
+}
+#endif
+
 // Superseded contraction kernels (variants 0, 1, 4..8) and timing-only ablation builds: compiled only into
 // libraries built with -DGSW_DIAGNOSTIC_BUILDS, for A/B timing.  The shipped library holds the default
 // kernel (variant 9) and the simple kernel below (variants 2, 3) as an independent cross-check.
@@ -1414,6 +1456,21 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
             break;
 #endif
         default: {
+#ifdef GSW_EXP_PERSIST
+            if (const char *e = getenv("GSW_PERSIST"); e && e[0] == '1') {
+                void *cnt = nullptr;
+                hipError_t pe = hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_persist_count));
+                if (pe == hipSuccess) pe = hipMemsetAsync(cnt, 0, sizeof(unsigned) * 8, stream);
+                if (pe != hipSuccess) return pe;
+                grid = dim3(512);
+                constexpr int kLds = rowblock_lds_bytes<4>();
+                if (!fp) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingZpow2, 0>), 256, kLds);
+                else if (a.scale_mode == 2) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 2>), 256, kLds);
+                else if (a.scale_mode == 1) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 1>), 256, kLds);
+                else return hipErrorInvalidValue;
+                break;
+            }
+#endif
 #ifdef GSW_EXP_ONEWG
             constexpr int kSkewLds = rowblock_lds_bytes<4>() + 24 * 1024;  // experiment: one workgroup per CU
 #else
