@@ -118,18 +118,25 @@ int gsw_flatten(gsw_ctx *ctx, uint32_t *d_mat, int rows, int cols);
 int gsw_add(gsw_ctx *ctx, const uint32_t *d_a, const uint32_t *d_b, uint32_t *d_out, size_t count);
 int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t count);
 /* mult (gsw_impl.rs:104-111, default features) and nand (gsw_impl.rs:114-123): the dim x dim x dim product
- * over R for arbitrary entries.  When dim is the context's N and the left operand has the reference's own
- * ciphertext format -- BitDecomp(R * A) + mu * I (gsw_impl.rs:27-42): entries 0 / 1 everywhere off the
- * diagonal -- the product runs as B * C2 + diag(d) * C2 on the int8-MFMA contraction (B the binary part, d the
- * diagonal entries other than 0 / 1); any other operand takes the plain dim^3 kernel.  The form is detected
- * on the device (one pass over C1 and a host synchronisation per call); results are identical. */
+ * over R for arbitrary entries.  Three kernels, identical results:
+ *  1. dim is the context's N and the left operand has the reference's own ciphertext format -- BitDecomp(R * A) +
+ *     mu * I (gsw_impl.rs:27-42): entries 0 / 1 everywhere off the diagonal -- : B * C2 + diag(d) * C2 on the binary x
+ *     digit int8-MFMA contraction (B the binary part, d the diagonal entries other than 0 / 1).  The form is detected
+ *     on the device (one pass over C1 and a host synchronisation per call).
+ *  2. any other left operand (what mult(mult(a, b), c) multiplies by in the reference's default build, which never
+ *     flattens: Cargo.toml:16-17): both operands split into four signed base-256 digits, sixteen digit x digit
+ *     int8-MFMA products with exact int32 accumulation, recombined mod q.  Needs 4 * pad^2 bytes of workspace for the
+ *     right operand (pad = dim rounded up to 64) plus 4 * pad bytes per left-operand row it takes at a time, within the
+ *     workspace limit; dim < 32768.
+ *  3. the plain dim^3 kernel: small matrices (below 1024 rows by default), or when the workspace limit rules out 2. */
 int gsw_mul_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
 int gsw_nand_dense(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim);
-/* 0: every dense product on the plain kernel (A/B timing, cross-checks); 1 (default): the MFMA path from
- * 1024 rows up, where it pays (N = 341: 0.06 ms against 0.02 ms plain; N = 7967: 3.2 ms against 78 ms);
- * 2: the MFMA path whenever the left operand has the form */
+/* 0: every dense product on the plain kernel (A/B timing, cross-checks); 1 (default): the MFMA kernels from
+ * 1024 rows up, where they pay (N = 341: 0.06 ms against 0.02 ms plain; N = 7967: 3.2 ms against 78 ms);
+ * 2: the MFMA kernels at any size */
 int gsw_ctx_set_dense_fast(gsw_ctx *ctx, int enable);
-/* which kernel the last dense product of this context used: 0 = plain dim^3, 1 = MFMA contraction */
+/* which kernel the last dense product of this context used: 0 = plain dim^3, 1 = binary x digit contraction
+ * (flattened left operand), 2 = digit x digit products (arbitrary entries) */
 int gsw_ctx_last_dense_path(const gsw_ctx *ctx);
 /* Test aid, no counterpart in the reference.  How the last contraction launch of this context recombined its four
  * limb sums: 1 = the 32-bit form with the branch-free epilogue on interior tiles (every benchmark shape), 0 = the

@@ -81,8 +81,11 @@ def test_engine_on_the_reference_held_products():
         if case["op"] == "matmul":
             b = np.array(case["b"], dtype=np.uint32)
             assert np.array_equal(gsw.mult_dense(a, b), expect), case["cite"]
-            assert gsw.last_dense_path() == 0  # arbitrary entries: the plain dim^3 kernel
+            assert gsw.last_dense_path() == 0  # arbitrary entries, small: the plain dim^3 kernel
             want = (np.eye(a.shape[0], dtype=np.int64) - expect.astype(np.int64)) % ring.q
+            assert np.array_equal(gsw.nand_dense(a, b), want.astype(np.uint32)), case["cite"]
+            gsw.set_dense_fast(2)  # and on the digit x digit MFMA products
+            assert np.array_equal(gsw.mult_dense(a, b), expect) and gsw.last_dense_path() == 2, case["cite"]
             assert np.array_equal(gsw.nand_dense(a, b), want.astype(np.uint32)), case["cite"]
         else:
             vec = np.array(case["b"], dtype=np.uint32)

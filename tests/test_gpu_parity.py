@@ -508,7 +508,20 @@ def test_dense_ops_arbitrary_entries(oracle, tfhe_amd, ring_name):
     a = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
     b = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
     _assert_equal(gsw.mult_dense(a, b), og.mult(a, b), "mult_dense")
+    assert gsw.last_dense_path() == 0  # small: the plain kernel by default
     _assert_equal(gsw.nand_dense(a, b), og.nand(a, b), "nand_dense")
+    # the same on sixteen signed-digit int8 products (MFMA), forced at this size; extreme entries too
+    gsw.set_dense_fast(2)
+    _assert_equal(gsw.mult_dense(a, b), og.mult(a, b), "mult_dense, digit products")
+    assert gsw.last_dense_path() == 2
+    _assert_equal(gsw.nand_dense(a, b), og.nand(a, b), "nand_dense, digit products")
+    top = np.full((dim, dim), ring_o.q - 1, dtype=np.uint32)
+    edge = np.array([v for v in _EDGE_Z32 if v < ring_o.q], dtype=np.uint32)
+    e1, e2 = edge[rng.integers(0, len(edge), size=(dim, dim))], edge[rng.integers(0, len(edge), size=(dim, dim))]
+    for x, y, what in ((top, top, "all q - 1"), (e1, e2, "edge values"), (top, b, "q - 1 times random"), (a, np.zeros_like(a), "zero")):
+        _assert_equal(gsw.mult_dense(x, y), og.mult(x, y), f"digit products, {what}")
+        assert gsw.last_dense_path() == 2
+    gsw.set_dense_fast(1)
     _assert_equal(gsw.add_dense(a, b), og.add(a, b), "add_dense")
     _assert_equal(gsw.mult_const_dense(a, ring_o.q - 2), og.mult_const(a, ring_o.q - 2), "mult_const_dense")
     comp = rng.integers(0, ring_o.q, size=(7, 5), dtype=np.uint64).astype(np.uint32)
@@ -523,6 +536,67 @@ def test_dense_ops_arbitrary_entries(oracle, tfhe_amd, ring_name):
     _assert_equal(gsw.flatten_matrix(small), oracle.flatten_matrix(ring_o, small), "flatten")
     ones = np.ones((1, ring_o.ell), dtype=np.uint32)
     assert gsw.bit_decomp_inv_matrix(ones)[0, 0] == oracle.bit_decomp_inv_matrix(ring_o, ones)[0, 0]
+
+
+@pytest.mark.parametrize("ring_name,dim", [("fp", 1500), ("z32", 1100), ("z30", 1030), ("fp", 64), ("fp", 65), ("z32", 1)])
+def test_dense_mult_arbitrary_left_operand_on_digit_products(oracle, tfhe_amd, ring_name, dim):
+    """mult / nand (gsw_impl.rs:104-123) with a left operand of arbitrary entries -- what mult(mult(a, b), c) is in
+    the reference's default build -- on the digit x digit MFMA products: whole products against the oracle at
+    sizes with ragged tiles (dim not a multiple of 64), the largest accumulators the size allows (all entries
+    q - 1 in one row band), and the default policy (from 1024 rows up) against the plain kernel."""
+    ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
+    gsw = tfhe_amd.GSW(ring_d, 2, 2 * ring_d.ell)
+    og = oracle.GSW(ring_o, 2, 2 * ring_o.ell)
+    rng = np.random.default_rng(dim)
+    a = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64).astype(np.uint32)
+    a[: min(dim, 20)] = ring_o.q - 1
+    b[:, : min(dim, 20)] = ring_o.q - 1
+    if dim > 70:
+        a[64:70] = 0x7F7F7F7F % ring_o.q  # every digit 127
+        b[:, 64:70] = 0x7F7F7F7F % ring_o.q
+    expect = oracle.matmul(ring_o, a, b)
+    got = gsw.mult_dense(a, b)
+    assert gsw.last_dense_path() == (2 if dim >= 1024 else 0)
+    _assert_equal(got, expect, f"default policy, dim {dim}")
+    gsw.set_dense_fast(2)
+    _assert_equal(gsw.mult_dense(a, b), expect, f"digit products, dim {dim}")
+    assert gsw.last_dense_path() == 2
+    want_nand = ((np.eye(dim, dtype=np.int64) - expect.astype(np.int64)) % ring_o.q).astype(np.uint32)
+    _assert_equal(gsw.nand_dense(a, b), want_nand, f"nand, digit products, dim {dim}")
+    gsw.set_dense_fast(0)
+    _assert_equal(gsw.mult_dense(a, b), expect, "plain kernel")
+    assert gsw.last_dense_path() == 0
+
+
+def test_dense_mult_arbitrary_left_operand_n256_sampled_rows_and_slabs(oracle, tfhe_amd):
+    """N = 7967 (n = 256): arbitrary left operand on the digit x digit products, sampled rows against the oracle; the
+    same product with a workspace limit that forces the left operand through in several row slabs."""
+    from tfhe_amd import _lib
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    n = 256
+    gsw = tfhe_amd.GSW(ring_d, n, n * 31)
+    eng, L = gsw.engine, _lib.lib()
+    dim = eng.big_n
+    d_a, d_b, d_o, d_o2 = (eng.alloc_u32(dim * dim) for _ in range(4))
+    _lib.check(L.gsw_fill_uniform(eng.handle, 21, 1, 0, ring_o.q - 1, 0, d_a.ptr, dim * dim))
+    _lib.check(L.gsw_fill_uniform(eng.handle, 21, 2, 0, ring_o.q - 1, 0, d_b.ptr, dim * dim))
+    _lib.check(L.gsw_mul_dense(eng.handle, d_a.ptr, d_b.ptr, d_o.ptr, dim))
+    assert gsw.last_dense_path() == 2
+    a = d_a.download(np.uint32, dim * dim).reshape(dim, dim)
+    b = d_b.download(np.uint32, dim * dim).reshape(dim, dim)
+    got = d_o.download(np.uint32, dim * dim).reshape(dim, dim)
+    rows = [0, 1, 63, 64, 4095, 4096, 4097, dim - 65, dim - 1]
+    _assert_equal(got[rows], oracle.matmul(ring_o, a[rows], b), "sampled rows of the N = 7967 product")
+    # 256 MB of right-operand planes + room for 1024 left-operand rows at a time: eight slabs
+    pad = (dim + 63) // 64 * 64
+    _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, 4 * pad * pad + 4 * pad * 1024))
+    _lib.check(L.gsw_nand_dense(eng.handle, d_a.ptr, d_b.ptr, d_o2.ptr, dim))
+    assert gsw.last_dense_path() == 2
+    got2 = d_o2.download(np.uint32, dim * dim).reshape(dim, dim)
+    want = ((np.eye(dim, dtype=np.int64) - got.astype(np.int64)) % ring_o.q).astype(np.uint32)
+    _assert_equal(got2, want, "nand through row slabs vs I - product")
 
 
 @pytest.mark.parametrize("ring_name", ["fp", "z8"])
@@ -551,7 +625,8 @@ def test_dense_mult_of_reference_format_ciphertexts_runs_on_mfma(oracle, tfhe_am
     """FheScheme::mult / nand (gsw_impl.rs:104-123) on the reference's own N x N ciphertexts,
     BitDecomp(R * A) + mu * I (gsw_impl.rs:27-42): the left operand is 0 / 1 off the diagonal, so the product
     takes the MFMA contraction (path 1) and must equal the oracle's plain N^3 product; the right operand is
-    arbitrary (a previous product included).  Left operands that do not fit the form take the plain kernel."""
+    arbitrary (a previous product included).  Left operands that do not fit the form take the digit x digit MFMA
+    products (path 2), or the plain kernel when the MFMA kernels are switched off."""
     ring_o, ring_d = _rings(oracle, tfhe_amd)[ring_name]
     m = n * ring_o.ell
     og = oracle.GSW(ring_o, n, m, seed=n, check_max=False)
@@ -579,12 +654,12 @@ def test_dense_mult_of_reference_format_ciphertexts_runs_on_mfma(oracle, tfhe_am
         osk = sk
         prod = gsw.mult_dense(og.encrypt(pk, 1), og.encrypt(pk, 1))
         assert og.decrypt(osk, prod) == 1
-    # one entry off the diagonal that is not 0 / 1: the plain kernel, same product
+    # one entry off the diagonal that is not 0 / 1: the digit x digit products, same product
     if ring_o.q > 2:
         odd = c1.copy()
         odd[3, big_n - 1] = 2
         _assert_equal(gsw.mult_dense(odd, anything), og.mult(odd, anything), "misfit left operand")
-        assert gsw.last_dense_path() == 0
+        assert gsw.last_dense_path() == 2
     # extreme diagonals and an all-ones left operand
     ones = np.ones((big_n, big_n), dtype=np.uint32)
     np.fill_diagonal(ones, ring_o.q - 1)

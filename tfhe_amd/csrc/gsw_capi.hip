@@ -138,7 +138,8 @@ struct gsw_ctx {
     size_t ws_limit;
     uint64_t n_prepared, n_products;  // right operands prepared / products contracted since creation
     int dense_fast;        // MFMA path of gsw_mul_dense / gsw_nand_dense: 0 never, 1 from 1024 rows up, 2 whenever the form fits
-    int last_dense_path;   // 0 = plain dim^3 kernel, 1 = MFMA contraction (what the last dense product used)
+    int last_dense_path;   // what the last dense product used: 0 = plain dim^3 kernel, 1 = binary x digit contraction
+                           // (flattened left operand), 2 = digit x digit products (arbitrary entries)
     int last_combine;      // recombination of the last contraction launch: 1 = 32-bit, 0 = 64-bit on every tile, -1 = none yet
     void *static_scratch;  // this GPU's copy of the library's static scratch array (gsw_mul_gadget_batch_static)
     bool in_static_call;   // inside gsw_mul_gadget_batch_static: nothing may allocate, not even timing events
@@ -730,8 +731,9 @@ int gsw_mult_const(gsw_ctx *ctx, uint32_t *d_inout, uint32_t constant, size_t co
 // mult / nand on the reference's own N x N matrices.  A left operand in the reference's ciphertext format
 // (entries 0 / 1 off the diagonal: BitDecomp(R * A) + mu * I, gsw_impl.rs:27-42) goes through the int8-MFMA
 // contraction with an N-column right operand plus a diagonal term; anything else -- arbitrary entries, a
-// dimension other than the context's N, a prepared operand beyond the workspace limit -- through the plain
-// dim^3 kernel.  Same results either way (both are the exact product over the ring).
+// dimension other than the context's N -- through sixteen signed-digit int8 products on MFMA; small matrices, or
+// operands whose digit planes exceed the workspace limit, through the plain dim^3 kernel.  Same results every way
+// (all are the exact product over the ring).
 static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c2, uint32_t *d_out, int dim, int nand) {
     ScopedRange range("gsw_mul_dense");
     if (!ctx || !d_c1 || !d_c2 || !d_out || dim < 0) return fail(GSW_E_INVALID, "bad argument");
@@ -812,6 +814,33 @@ static int dense_product(gsw_ctx *ctx, const uint32_t *d_c1, const uint32_t *d_c
             if (counts[1] != 0 || nand)
                 HIP_TRY(gswk::launch_dense_fixup(ctx->ring, d_out, d_c2, diag, dim, nand, ctx->stream));
             ctx->last_dense_path = 1;
+            return GSW_OK;
+        }
+    }
+    // Any other left operand: sixteen signed-digit int8 products on MFMA (dense_limb_gemm_kernel), when the digit
+    // planes of the right operand and of at least 64 rows of the left one fit the workspace; the left operand
+    // goes through in row slabs.
+    if (worth_it && dim > 0 && dim < 32768) {
+        const size_t pad = (size_t)gswk::dense_limb_pad(dim);
+        const size_t rhs_bytes = 4 * pad * pad;
+        if (rhs_bytes + 4 * pad * 64 <= ctx->ws_limit) {
+            size_t slab = (ctx->ws_limit - rhs_bytes) / (4 * pad) / 64 * 64;  // rows of the left operand per pass
+            if (slab >= pad) slab = pad;
+            else if (slab >= 4096) slab = slab / 4096 * 4096;  // whole placement groups of 64 row tiles
+            if (int rc = ensure_workspace(ctx, rhs_bytes + 4 * pad * slab)) return rc;
+            uint8_t *rhs_planes = (uint8_t *)ctx->ws, *lhs_planes = rhs_planes + rhs_bytes;
+            ctx->n_prepared += 1;
+            {
+                ScopedTimer timer(ctx, 1, ctx->stream);
+                HIP_TRY(gswk::launch_dense_split_transposed(ctx->ring, d_c2, dim, rhs_planes, ctx->stream));
+            }
+            for (size_t r0 = 0; r0 < (size_t)dim; r0 += slab) {
+                const int rows = (int)((size_t)dim - r0 < slab ? (size_t)dim - r0 : slab);
+                HIP_TRY(gswk::launch_dense_split_rows(ctx->ring, d_c1, dim, (int)r0, rows, lhs_planes, ctx->stream));
+                ScopedTimer timer(ctx, 0, ctx->stream);
+                HIP_TRY(gswk::launch_dense_limb_gemm(ctx->ring, lhs_planes, rhs_planes, d_out, dim, (int)r0, rows, nand, ctx->stream));
+            }
+            ctx->last_dense_path = 2;
             return GSW_OK;
         }
     }

@@ -155,6 +155,17 @@ hipError_t launch_pack_flat_lhs(const RingDesc &ring, const uint32_t *c1, int di
 // out += diag(d) * c2, then out = I - out when nand
 hipError_t launch_dense_fixup(const RingDesc &ring, uint32_t *out, const uint32_t *c2, const uint32_t *diag, int dim,
                               int nand, hipStream_t stream);
+// Dense product with arbitrary entries as 4 x 4 signed-digit int8 products (see dense_limb_gemm_kernel).
+// dense_limb_pad: dim rounded up to the 64 x 64 tile.  Right operand: launch_dense_split_transposed writes its digit
+// planes [4][pad][pad] ([digit][column][k]); left operand: launch_dense_split_rows writes those of rows
+// row0 .. row0 + rows - 1 as [4][dense_limb_pad(rows)][pad]; launch_dense_limb_gemm computes those rows of the
+// product (nand: of I - product).  dim < 32768.
+int dense_limb_pad(int dim);
+hipError_t launch_dense_split_transposed(const RingDesc &ring, const uint32_t *src, int dim, uint8_t *planes, hipStream_t stream);
+hipError_t launch_dense_split_rows(const RingDesc &ring, const uint32_t *src, int dim, int row0, int rows, uint8_t *planes,
+                                   hipStream_t stream);
+hipError_t launch_dense_limb_gemm(const RingDesc &ring, const uint8_t *lhs_planes, const uint8_t *rhs_planes, uint32_t *out, int dim,
+                                  int row0, int rows, int nand, hipStream_t stream);
 // out[b * nrows + k] = <x_b[row0 + k, 0..cols), vec> mod q
 hipError_t launch_row_dot(const RingDesc &ring, const uint32_t *x, size_t stride, int ld, int cols, int row0,
                           int nrows, const uint32_t *vec, int batch, uint32_t *out, hipStream_t stream);

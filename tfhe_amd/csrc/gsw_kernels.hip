@@ -1903,6 +1903,216 @@ hipError_t launch_mul_dense(const RingDesc &ring, const uint32_t *a, const uint3
     return hipGetLastError();
 }
 
+// ---- dense product with arbitrary entries on MFMA: 4 x 4 signed-digit products.
+//
+// mult (gsw_impl.rs:104-111) on matrices that are not in the flattened form -- the reference's default build never
+// flattens (Cargo.toml:16-17), so mult(mult(a, b), c) multiplies by a left operand with arbitrary entries.  Both
+// operands are split into four signed base-256 digits (signed_digits): C1 = sum_a 256^a L_a, C2 = sum_b 256^b R_b, and
+//     C1 C2 = sum_d 256^d T_d,   T_d = sum_{a + b = d} L_a R_b,
+// sixteen int8 products with exact int32 accumulation (|T_d| <= 4 * 2^14 * dim < 2^31 for dim < 32768), seven
+// accumulators per output element (four for Z/2^M: 256^d vanishes mod 2^32 from d = 4 on, ten products).
+// dense_split_kernel writes the digit planes -- [digit][row][k] bytes for the left operand, [digit][column][k] for
+// the right one (transposed through LDS), k padded to 64 and rows / columns to 64 with zeros -- so that every
+// 16 x 64 MFMA fragment is 16 rows of 64 contiguous bytes.  dense_limb_gemm_kernel: workgroup tile 64 x 64, four
+// waves of 32 x 32, two LDS buffers of 32 fragments (LDS-DMA, fragment order, conflict-free 16-byte reads), one
+// barrier per 64 K slots; the XCD-aware order gives each XCD 8 row tiles x 8 column tiles at a time.
+
+constexpr int kDenseTile = 64;
+
+template <int RING, bool TRANSPOSE>
+__global__ __launch_bounds__(256) void dense_split_kernel(const uint32_t *src, int dim, int pad, uint8_t *planes) {
+    // planes: [4][pad][pad] bytes; element (i, k) of plane d = digit d of src[i][k] (TRANSPOSE: of src[k][i])
+    __shared__ uint32_t tile[kDenseTile][kDenseTile + 1];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * kDenseTile, k0 = blockIdx.x * kDenseTile;
+    // load 64 x 64 words with coalesced reads along the source's rows, digits already split
+    for (int e = tid; e < kDenseTile * kDenseTile; e += 256) {
+        const int y = e >> 6, x = e & 63;
+        // source row / column of this word
+        const int r = TRANSPOSE ? k0 + y : i0 + y, c = TRANSPOSE ? i0 + x : k0 + x;
+        const uint32_t v = (r < dim && c < dim) ? signed_digits<RING>(src[(size_t)r * dim + c]) : 0u;
+        if (TRANSPOSE) tile[x][y] = v;  // tile[i][k]
+        else tile[y][x] = v;
+    }
+    __syncthreads();
+    // every thread packs four consecutive k of one i into one dword per digit plane
+    const size_t plane = (size_t)pad * pad;
+    for (int e = tid; e < kDenseTile * (kDenseTile / 4); e += 256) {
+        const int i = e >> 4, kq = (e & 15) * 4;
+        const uint32_t w0 = tile[i][kq], w1 = tile[i][kq + 1], w2 = tile[i][kq + 2], w3 = tile[i][kq + 3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t packed = ((w0 >> (8 * d)) & 0xFFu) | (((w1 >> (8 * d)) & 0xFFu) << 8) |
+                                    (((w2 >> (8 * d)) & 0xFFu) << 16) | (((w3 >> (8 * d)) & 0xFFu) << 24);
+            *reinterpret_cast<uint32_t *>(planes + d * plane + (size_t)(i0 + i) * pad + k0 + kq) = packed;
+        }
+    }
+}
+
+template <int RING>
+__global__ __launch_bounds__(256, 2) void dense_limb_gemm_kernel(const uint8_t *lhs_planes, const uint8_t *rhs_planes, uint32_t *out,
+                                                                int dim, int pad, int row0, int rows, int nand, uint32_t mask,
+                                                                int col_tiles_n, int row_tiles_n) {
+    // lhs_planes holds rows row0 .. row0 + rows_pad - 1 of the left operand (a slab); out rows are absolute
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kND = RING == kRingFp ? 7 : 4;  // accumulators (powers of 256) per output element
+    constexpr int kStage = 32 * kFragBytes;      // 16 left + 16 right fragments
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // placement: an XCD (workgroups id mod 8) works on 8 row tiles x 8 column tiles at a time, row tile fastest
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int ct_groups = (col_tiles_n + 7) / 8;
+    const int per_group = 8 * 8;
+    const int grp = local / per_group, in = local % per_group;
+    const int rgrp = grp / ct_groups, cgrp = grp % ct_groups;
+    const int rt = (rgrp * 8 + (in & 7)) * 8 + xcd, ctile = cgrp * 8 + (in >> 3);
+    if (rt >= row_tiles_n || ctile >= col_tiles_n) return;
+    const int r_base = rt * kDenseTile, c_base = ctile * kDenseTile;  // r_base relative to the slab
+    const size_t lhs_plane = (size_t)(row_tiles_n * kDenseTile) * pad, rhs_plane = (size_t)pad * pad;
+    const int steps = pad / 64;
+    const int fr = lane & 15, fg = lane >> 4;  // fragment lane: row / column fr, K group fg
+
+    // this wave stages fragments 8 wave .. 8 wave + 7 of a stage: 0..15 left [row block][digit], 16..31 right [column block][digit]
+    const uint8_t *src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = wave * 8 + j, blk = (f & 15) >> 2, d = f & 3;
+        src[j] = f < 16 ? lhs_planes + d * lhs_plane + (size_t)(r_base + 16 * blk + fr) * pad + 16 * fg
+                        : rhs_planes + d * rhs_plane + (size_t)(c_base + 16 * blk + fr) * pad + 16 * fg;
+    }
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds(src[j] + (size_t)t * 64,
+                                             (__attribute__((address_space(3))) void *)(smem + buf * kStage + (wave * 8 + j) * kFragBytes),
+                                             16, 0, 0);
+    };
+    const int wr = wave >> 1, wc = wave & 1;  // this wave's 32 x 32 quadrant
+    v4i acc[2][2][kND];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int d = 0; d < kND; ++d) acc[i][j][d] = v4i{0, 0, 0, 0};
+
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < steps; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < steps) stage(t + 1, buf ^ 1);
+        const unsigned char *sa = smem + buf * kStage + lane * 16;
+        const unsigned char *sb = sa + 16 * kFragBytes;
+        v4i fa[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[i][a] = *reinterpret_cast<const v4i *>(sa + ((2 * wr + i) * 4 + a) * kFragBytes);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const v4i fb = *reinterpret_cast<const v4i *>(sb + ((2 * wc + j) * 4 + b) * kFragBytes);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a + b >= kND) continue;  // Z/2^M: 256^(a+b) vanishes
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][j][a + b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][a], fb, acc[i][j][a + b], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+    // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r_base + wr * 32 + i * 16 + 4 * fg + r, col = c_base + wc * 32 + j * 16 + fr;
+                if (row >= rows || col >= dim) continue;
+                uint32_t val;
+                if (RING == kRingFp) {
+                    // 256^d mod p for d = 4, 5, 6: 2^32 = 2, 2^40 = 2^9, 2^48 = 2^17; |sum| < 2^58, made positive by p 2^28
+                    const long long v = (long long)acc[i][j][0][r] + (long long)acc[i][j][1][r] * 256 + (long long)acc[i][j][2][r] * 65536 +
+                                        (long long)acc[i][j][3][r] * 16777216 + (long long)acc[i][j][4 % kND][r] * 2 +
+                                        (long long)acc[i][j][5 % kND][r] * 512 + (long long)acc[i][j][6 % kND][r] * 131072;
+                    val = fp_reduce64((unsigned long long)(v + ((long long)kFpP << 28)));
+                } else {
+                    val = ((uint32_t)acc[i][j][0][r] + ((uint32_t)acc[i][j][1][r] << 8) + ((uint32_t)acc[i][j][2][r] << 16) +
+                           ((uint32_t)acc[i][j][3][r] << 24)) & mask;
+                }
+                const int arow = row0 + row;
+                if (nand) {  // I - P (gsw_impl.rs:114-123)
+                    val = ring_sub<RING>(0u, val, mask);
+                    if (arow == col) val = ring_add<RING>(val, ring_from_u64<RING>(1ull, mask), mask);
+                }
+                out[(size_t)arow * dim + col] = val;
+            }
+}
+
+int dense_limb_pad(int dim) { return (dim + kDenseTile - 1) / kDenseTile * kDenseTile; }
+
+hipError_t launch_dense_split_transposed(const RingDesc &ring, const uint32_t *src, int dim, uint8_t *planes, hipStream_t stream) {
+    const int pad = dense_limb_pad(dim);
+    dim3 grid((unsigned)(pad / kDenseTile), (unsigned)(pad / kDenseTile));
+    if (ring.kind == kRingFp) hipLaunchKernelGGL((dense_split_kernel<kRingFp, true>), grid, dim3(256), 0, stream, src, dim, pad, planes);
+    else hipLaunchKernelGGL((dense_split_kernel<kRingZpow2, true>), grid, dim3(256), 0, stream, src, dim, pad, planes);
+    return hipGetLastError();
+}
+
+// The left operand's slab: rows row0 .. row0 + rows - 1 of a dim x dim matrix into planes [4][rows_pad][pad]
+template <int RING>
+__global__ __launch_bounds__(256) void dense_split_rows_kernel(const uint32_t *src, int dim, int pad, int row0, int rows, int rows_pad,
+                                                                uint8_t *planes) {
+    const size_t plane = (size_t)rows_pad * pad;
+    const size_t quads = (size_t)rows_pad * (pad / 4);
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+        const int i = (int)(q / (size_t)(pad / 4)), k = (int)(q - (size_t)i * (pad / 4)) * 4;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (i < rows && k + j < dim) ? signed_digits<RING>(src[(size_t)(row0 + i) * dim + k + j]) : 0u;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t packed = ((w[0] >> (8 * d)) & 0xFFu) | (((w[1] >> (8 * d)) & 0xFFu) << 8) |
+                                    (((w[2] >> (8 * d)) & 0xFFu) << 16) | (((w[3] >> (8 * d)) & 0xFFu) << 24);
+            *reinterpret_cast<uint32_t *>(planes + d * plane + (size_t)i * pad + k) = packed;
+        }
+    }
+}
+
+hipError_t launch_dense_split_rows(const RingDesc &ring, const uint32_t *src, int dim, int row0, int rows, uint8_t *planes,
+                                   hipStream_t stream) {
+    const int pad = dense_limb_pad(dim), rows_pad = dense_limb_pad(rows);
+    dim3 grid(grid_for((size_t)rows_pad * (pad / 4), 256)), block(256);
+    if (ring.kind == kRingFp)
+        hipLaunchKernelGGL(dense_split_rows_kernel<kRingFp>, grid, block, 0, stream, src, dim, pad, row0, rows, rows_pad, planes);
+    else
+        hipLaunchKernelGGL(dense_split_rows_kernel<kRingZpow2>, grid, block, 0, stream, src, dim, pad, row0, rows, rows_pad, planes);
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_limb_gemm(const RingDesc &ring, const uint8_t *lhs_planes, const uint8_t *rhs_planes, uint32_t *out, int dim,
+                                  int row0, int rows, int nand, hipStream_t stream) {
+    if (dim <= 0 || rows <= 0) return hipSuccess;
+    if (dim >= 32768) return hipErrorInvalidValue;  // int32 accumulators: 4 * 2^14 * dim < 2^31
+    const int pad = dense_limb_pad(dim);
+    const int row_tiles = dense_limb_pad(rows) / kDenseTile, col_tiles_n = pad / kDenseTile;
+    const long groups = (long)((row_tiles + 63) / 64) * ((col_tiles_n + 7) / 8);
+    const long blocks = groups * 64 * 8;
+    if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
+    const size_t lds = 2 * 32 * kFragBytes;
+    if (ring.kind == kRingFp)
+        hipLaunchKernelGGL(dense_limb_gemm_kernel<kRingFp>, dim3((unsigned)blocks), dim3(256), lds, stream, lhs_planes, rhs_planes, out,
+                           dim, pad, row0, rows, nand, ring.mask, col_tiles_n, row_tiles);
+    else
+        hipLaunchKernelGGL(dense_limb_gemm_kernel<kRingZpow2>, dim3((unsigned)blocks), dim3(256), lds, stream, lhs_planes, rhs_planes, out,
+                           dim, pad, row0, rows, nand, ring.mask, col_tiles_n, row_tiles);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ decrypt support
 //
 // <row, vec> mod q for a few rows of each batch entry: decrypt reads row ell-1

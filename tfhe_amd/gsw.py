@@ -595,7 +595,8 @@ class GSW:
         check(_lib.lib().gsw_ctx_set_dense_fast(self.engine.handle, int(mode)))
 
     def last_dense_path(self) -> int:
-        """Which kernel the last dense product used: 0 = the plain N^3 kernel, 1 = the MFMA contraction."""
+        """Which kernel the last dense product used: 0 = the plain N^3 kernel, 1 = the binary x digit MFMA contraction
+        (flattened left operand), 2 = the digit x digit MFMA products (arbitrary entries)."""
         return int(_lib.lib().gsw_ctx_last_dense_path(self.engine.handle))
 
     def last_combine(self) -> int:
@@ -605,8 +606,9 @@ class GSW:
 
     def mult_dense(self, c1, c2) -> np.ndarray:
         """src/gsw/gsw_impl.rs:104-111 (default features): the N x N x N product on the reference's own
-        matrices.  A left operand in the reference's ciphertext format (0 / 1 off the diagonal) runs on the
-        MFMA contraction, anything else on the plain kernel; the results are the same."""
+        matrices.  A left operand in the reference's ciphertext format (0 / 1 off the diagonal) runs on the binary x
+        digit MFMA contraction, any other on sixteen digit x digit MFMA products, small matrices on the plain
+        kernel; the results are the same."""
         return self._dense_binary(_lib.lib().gsw_mul_dense, c1, c2)
 
     def nand_dense(self, c1, c2) -> np.ndarray:

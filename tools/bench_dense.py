@@ -51,6 +51,24 @@ def main():
                 result[f"{name}_tops_int8_equiv"] = 2.0 * big_n ** 3 * 4 / (ms * 1e-3) / 1e12
             result["identical"] = bool(torch.equal(out, ref))
             result["speedup"] = result["plain_ms"] / result["mfma_ms"]
+            # an arbitrary left operand (what mult(mult(a, b), c) multiplies by without flatten): sixteen signed-digit
+            # int8 products on MFMA against the plain kernel (whose result `ref2` is computed once)
+            c1.copy_(torch.randint(0, 2147483647, (big_n, big_n), dtype=torch.int32, device=dev, generator=g))
+            for name, fast, reps in (("digits", 2, 3), ("plain_arbitrary", 0, 1 if n > 64 else 3)):
+                _lib.check(L.gsw_ctx_set_dense_fast(eng.handle, fast))
+                dst = out if fast else ref
+                _lib.check(L.gsw_mul_dense(eng.handle, c1.data_ptr(), c2.data_ptr(), dst.data_ptr(), big_n))
+                assert L.gsw_ctx_last_dense_path(eng.handle) == (2 if fast else 0)
+                start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record(stream)
+                for _ in range(reps):
+                    _lib.check(L.gsw_mul_dense(eng.handle, c1.data_ptr(), c2.data_ptr(), dst.data_ptr(), big_n))
+                stop.record(stream)
+                stop.synchronize()
+                result[f"{name}_ms"] = start.elapsed_time(stop) / reps
+            result["digits_tops_int8"] = 2.0 * big_n ** 3 * 16 / (result["digits_ms"] * 1e-3) / 1e12
+            result["digits_identical"] = bool(torch.equal(out, ref))
+            result["digits_speedup"] = result["plain_arbitrary_ms"] / result["digits_ms"]
         print(json.dumps(result), flush=True)
 
 
