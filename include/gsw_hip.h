@@ -213,7 +213,10 @@ int gsw_eval_circuit(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_
  * caller's array (in/out): set them for entries filled otherwise (gsw_encrypt_batch_prepared, gsw_prepare_rhs) and
  * clear them for slots changed behind the library's back.  A run of independent products is one contraction
  * launch straight out of the cache.  A list the checks reject leaves flags and pool untouched; a failure after
- * launches have begun clears every flag. */
+ * launches have begun clears every flag.  The flags are only as good as the caller's bookkeeping: ANY other write
+ * into a pool slot (gsw_encrypt_batch*, gsw_upload_compact, gsw_add / gsw_mult_const, a product or gsw_eval_circuit
+ * with the pool as output, a copy) must clear that slot's flag, or later gates multiply by the stale prepared
+ * operand without any error.  (The Python mirror, tfhe_amd/gsw.py, binds a cache to its pool and does this itself.) */
 int gsw_eval_circuit_cached(gsw_ctx *ctx, uint32_t *d_pool, size_t slot_stride, uint32_t n_slots, void *d_prepared_pool,
                             uint8_t *h_valid, const gsw_gate *h_gates, size_t n_gates);
 

@@ -234,6 +234,40 @@ def test_chain_over_fresh_encryptions_in_prepared_form_prepares_nothing(oracle, 
     assert gsw.decrypt_batch(sk, pool, slot=final, count=chains).tolist() == want
 
 
+def test_writes_into_the_pool_invalidate_its_prepared_cache(oracle, tfhe_amd):
+    """A slot overwritten behind a cached gate list -- by encrypt_batch without cache=, by mult_const, by an uncached
+    gate list -- loses its flag, so the next cached list prepares it again instead of multiplying by the stale
+    prepared operand; a cache cannot serve two pools."""
+    ring_o, ring_d = oracle.fp(), tfhe_amd.Fp()
+    n = 10
+    gsw = tfhe_amd.GSW(ring_d, n, 310, seed=77)
+    og = oracle.GSW(ring_o, n, 310)
+    sk, pk = gsw.keygen()
+    pool = gsw.encrypt_batch(pk, [1, 1, 0, 0, 0, 0])
+    cache = tfhe_amd.PreparedCache(gsw.engine, pool.batch, pool=pool)
+    gsw.eval_circuit(pool, [("mult", 0, 1, 2)], cache=cache)  # prepares slot 1
+    assert cache.valid[1] == 1 and gsw.decrypt_batch(sk, pool, slot=2, count=1)[0] == 1
+    gsw.encrypt_batch(pk, [0], out=pool, slot=1)  # slot 1 now encrypts 0, written without the cache
+    assert cache.valid[1] == 0
+    gsw.eval_circuit(pool, [("mult", 0, 1, 3)], cache=cache)
+    host = pool.to_compact()
+    assert np.array_equal(host[3], og.mul_gadget(host[0], host[1]))
+    assert gsw.decrypt_batch(sk, pool, slot=3, count=1)[0] == 0
+    assert cache.valid[1] == 1
+    gsw.eval_circuit(pool, [("add", 0, 0, 1)])  # an uncached list writes slot 1
+    assert not cache.valid.any()
+    gsw.eval_circuit(pool, [("mult", 0, 1, 4)], cache=cache)
+    host = pool.to_compact()
+    assert np.array_equal(host[4], og.mul_gadget(host[0], host[1]))
+    gsw.mult_const(pool, 3)  # in place on the whole batch
+    assert not cache.valid.any()
+    other = gsw.encrypt_batch(pk, [1] * 6)
+    with pytest.raises(ValueError, match="another pool"):
+        gsw.eval_circuit(other, [("mult", 0, 1, 2)], cache=cache)
+    with pytest.raises(ValueError, match="already has"):
+        tfhe_amd.PreparedCache(gsw.engine, pool.batch, pool=pool)
+
+
 def test_bad_gates_are_rejected(tfhe_amd):
     gsw = tfhe_amd.GSW(tfhe_amd.Fp(), 2, 62, seed=1)
     pool = tfhe_amd.Ciphertext(gsw.engine, 4)

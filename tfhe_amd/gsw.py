@@ -150,6 +150,16 @@ class Ciphertext:
         self.engine = engine
         self.batch = int(batch)
         self.buf = buf if buf is not None else engine.alloc_u32(engine.compact_elems * self.batch)
+        self._cache = None  # weak reference to the PreparedCache bound to this batch, if any
+
+    def invalidate(self, slot: int = 0, count: Optional[int] = None) -> None:
+        """Entries slot .. slot + count - 1 are about to change: a PreparedCache bound to this batch forgets their
+        prepared forms.  Every method of this module that writes into an existing batch calls it; code that
+        writes through `buf` or a raw pointer must call it itself."""
+        cache = self._cache() if self._cache is not None else None
+        if cache is not None:
+            count = self.batch - slot if count is None else count
+            cache.valid[slot:slot + count] = 0
 
     @property
     def ptr(self) -> int:
@@ -213,12 +223,33 @@ class Ciphertext:
 
 class PreparedCache:
     """Prepared right operands beside a pool of ciphertexts (gsw_eval_circuit_cached): entry s is the prepared form
-    of pool slot s when valid[s] is set."""
+    of pool slot s when valid[s] is set.  A cache belongs to one pool: it is bound to the first batch it is used
+    with (or to `pool` here), every writer of this module into that batch clears the flags of the entries it
+    changes, and using the cache with another batch is refused."""
 
-    def __init__(self, engine: Engine, slots: int):
+    def __init__(self, engine: Engine, slots: int, pool: Optional["Ciphertext"] = None):
         self.engine, self.slots = engine, int(slots)
         self.buf = engine.alloc(engine.prepared_bytes * self.slots)
         self.valid = np.zeros(self.slots, dtype=np.uint8)
+        self._pool = None
+        if pool is not None:
+            self.bind(pool)
+
+    def bind(self, pool: "Ciphertext") -> None:
+        import weakref
+
+        bound = self._pool() if self._pool is not None else None
+        if bound is pool:
+            return
+        if bound is not None:
+            raise ValueError("this prepared-operand cache belongs to another pool")
+        if self.slots != pool.batch:
+            raise ValueError("the prepared-operand cache must have one entry per pool slot")
+        other = pool._cache() if pool._cache is not None else None
+        if other is not None and other is not self:
+            raise ValueError("the pool already has a prepared-operand cache")
+        self._pool = weakref.ref(pool)
+        pool._cache = weakref.ref(self)
 
     def entry_ptr(self, slot: int) -> int:
         return self.buf.ptr + self.engine.prepared_bytes * slot
@@ -420,8 +451,9 @@ class GSW:
                 raise ValueError(f"entries {slot}..{slot + batch - 1} do not fit a batch of {out.batch}")
             ct, dst = out, out.entry_ptr(slot)
         target = ct.ptr if dst is None else dst
-        if cache is not None and slot + batch > cache.slots:
-            raise ValueError("the prepared-operand cache is shorter than the pool range written")
+        if cache is not None:
+            cache.bind(ct)  # one cache per pool; refuses a cache that belongs to another batch
+        ct.invalidate(slot, batch)  # whatever cache the batch has: these entries change (flags set again on success)
         prepared_out = None if cache is None else cache.entry_ptr(slot)
         if rbits is None:
             # the bits are drawn inside the call, chunk by chunk beside the contraction: no N x m matrix per entry
@@ -522,6 +554,7 @@ class GSW:
 
     def mult_const(self, ct: Ciphertext, constant: int) -> None:
         """src/gsw/gsw_impl.rs:97-101: in place, like the reference."""
+        ct.invalidate()
         check(_lib.lib().gsw_mult_const(self.engine.handle, ct.ptr, int(constant), ct.stride * ct.batch))
 
     def _product(self, c1: Ciphertext, c2: Ciphertext, flags: int) -> Ciphertext:
@@ -566,10 +599,10 @@ class GSW:
         arr = self.encode_gates(gates)
         gate_ptr = arr.ctypes.data_as(C.POINTER(_lib.Gate))
         if cache is None:
+            pool.invalidate()  # gates write slots behind the back of a cache the pool may have
             check(_lib.lib().gsw_eval_circuit(self.engine.handle, pool.ptr, pool.stride, pool.batch, gate_ptr, len(arr)))
             return
-        if cache.slots != pool.batch:
-            raise ValueError("the prepared-operand cache must have one entry per pool slot")
+        cache.bind(pool)
         check(_lib.lib().gsw_eval_circuit_cached(self.engine.handle, pool.ptr, pool.stride, pool.batch, cache.buf.ptr,
                                                  cache.valid.ctypes.data, gate_ptr, len(arr)))
 
