@@ -184,6 +184,14 @@ static void device_keygen_and_dense_mfma_path() {
     EXPECT(a.last_dense_path() == 1 && fast.data == plain.data);
     EXPECT(a.decrypt(dev.first, a.mult(c1, c0)) == 0 && a.decrypt(dev.first, a.nand(c1, c1)) == 0);
     EXPECT(a.decrypt(dev.first, a.nand(c1, c0)) == 1 && a.last_dense_path() == 1);
+    // a product of products -- the reference's default build never flattens (Cargo.toml:16-17), so the left operand has
+    // arbitrary entries: the digit x digit MFMA products, against the plain kernel
+    DMatrix pp = a.mult(fast, c1);
+    EXPECT(a.last_dense_path() == 2);
+    a.set_dense_mode(0);
+    DMatrix pp_plain = a.mult(fast, c1);
+    EXPECT(a.last_dense_path() == 0 && pp.data == pp_plain.data);
+    a.set_dense_mode(2);
     // gates over a pool with the prepared-operand cache: NAND(1, 1) = 0, then NAND(0, 1) = 1
     CompactCiphertext pool{DeviceBuffer(a.ctx(), gsw_ctx_compact_elems(a.ctx()) * 4 * 4), 4};
     for (int sl = 0; sl < 2; ++sl) {
