@@ -160,3 +160,40 @@ def test_gate_lists_on_random_pools(oracle, pkg, seed):
     got = pool2.to_compact()
     for s in range(slots):
         assert np.array_equal(got[s], model[s]), f"seed {seed} (cached): {ring} n={n} slot {s} after {gates}"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_dense_products_on_random_sizes(oracle, pkg, seed):
+    """mult / nand (gsw_impl.rs:104-123) on square matrices of random size with arbitrary entries, on the digit x digit
+    MFMA products and on the plain kernel, against the oracle's exact product; entries drawn from the whole ring,
+    from its extremes, or sparse."""
+    rng = np.random.default_rng(0xDE75 + seed)
+    ring = ("fp", 31) if seed % 2 == 0 else ("z", int(rng.integers(1, 33)))
+    ring_o, ring_d = _rings(oracle, pkg, ring)
+    dim = int(rng.integers(1, 200)) if seed % 4 else int(rng.integers(200, 700))
+    gsw = pkg.GSW(ring_d, 1, ring_d.ell)
+    kind = seed % 3
+    if kind == 0:
+        a = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64)
+        b = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64)
+    elif kind == 1:  # extremes: 0, 1, q - 1, q - 2 and the values around the digit boundaries
+        pick = np.array(sorted({0, 1 % ring_o.q, ring_o.q - 1, max(ring_o.q - 2, 0), 127 % ring_o.q, 128 % ring_o.q,
+                                0x7F7F7F7F % ring_o.q, 0x7F7F7F80 % ring_o.q, 0x80808080 % ring_o.q}), dtype=np.uint64)
+        a = pick[rng.integers(0, len(pick), size=(dim, dim))]
+        b = pick[rng.integers(0, len(pick), size=(dim, dim))]
+    else:  # sparse left operand with a few large entries
+        a = np.zeros((dim, dim), dtype=np.uint64)
+        idx = rng.integers(0, dim, size=(max(dim, 4), 2))
+        a[idx[:, 0], idx[:, 1]] = rng.integers(0, ring_o.q, size=len(idx), dtype=np.uint64)
+        b = rng.integers(0, ring_o.q, size=(dim, dim), dtype=np.uint64)
+    a, b = a.astype(np.uint32), b.astype(np.uint32)
+    expect = oracle.matmul(ring_o, a, b)
+    want_nand = ((np.eye(dim, dtype=np.int64) - expect.astype(np.int64)) % ring_o.q).astype(np.uint32)
+    for mode, path in ((2, 2), (0, 0)):
+        gsw.set_dense_fast(mode)
+        got = gsw.mult_dense(a, b)
+        # a left operand that happens to be 0 / 1 off the diagonal takes the binary x digit contraction only when its
+        # size is the context's N (never here: N = 2 ell)
+        assert gsw.last_dense_path() == path, (seed, mode)
+        assert np.array_equal(got, expect), (seed, ring, dim, mode)
+        assert np.array_equal(gsw.nand_dense(a, b), want_nand), (seed, ring, dim, mode, "nand")
