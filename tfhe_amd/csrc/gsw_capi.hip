@@ -162,7 +162,7 @@ namespace {
 // (GSW_BIT_SCALE=0 in the environment turns them off for A/B timing and cross-checks)
 int scale_mode_for(const gsw_ctx *ctx, int e4) {
     static const bool on = [] { const char *e = getenv("GSW_BIT_SCALE"); return !(e && e[0] == '0'); }();
-    return on && ctx->gemm_variant == 9 ? gswk::bit_scale_mode(ctx->ring, e4) : 0;
+    return on && (ctx->gemm_variant == 9 || ctx->gemm_variant == 12) ? gswk::bit_scale_mode(ctx->ring, e4) : 0;
 }
 
 int use_device(const gsw_ctx *ctx) {
@@ -364,13 +364,16 @@ int gsw_ctx_create(gsw_ctx **out, int ring_kind, int log2q, int n, int m, int de
 #ifdef GSW_EXP_TALL
     known = known || ctx->gemm_variant == 10 || ctx->gemm_variant == 11;
 #endif
+#ifdef GSW_EXP_WIDE8
+    known = known || ctx->gemm_variant == 12;
+#endif
     if (!known) {
         delete ctx;
         return fail(GSW_E_INVALID, "GSW_GEMM_VARIANT must be 9 (default), 2 or 3 (simple cross-check kernels); the "
                                    "superseded kernels exist only in a -DGSW_DIAGNOSTIC_BUILDS library");
     }
     ctx->packed_tail = (ctx->gemm_variant == 2 || ctx->gemm_variant == 3) ? gswk::kTailNone
-                                                                          : gswk::tail_mode(ctx->width, ctx->gemm_variant == 9);
+                                                                          : gswk::tail_mode(ctx->width, ctx->gemm_variant == 9 || ctx->gemm_variant == 12);
     if (int rc = resolve_static_scratch(device, &ctx->static_scratch)) {  // `device` is current (hipSetDevice above)
         delete ctx;
         return rc;

@@ -862,16 +862,38 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
 #define GSW_SKEW_INTERLEAVE 1
 #endif
 
-template <int RING, int SCALE>
+// Loads a wave may leave in flight when it enters a stage in slot `slot` of a super-stage (`first`: the very first
+// stage).  A stage issues, in this order, portion q = 0..3: piece q of the next super-stage's left operand when the
+// stage opens a super-stage (slot 0), then round q of the right operand DEPTH - 1 stages ahead when q < rounds.
+// Entering stage t needs the right operand of stage t (issued DEPTH - 1 stages ago) and, in slot 0, the left
+// operand issued four stages ago; everything issued after those may still be under way.
+constexpr int skew_loads_in_flight(int rounds, int depth, int slot, bool first) {
+    if (first) return (depth - 2) * rounds;  // the prologue: left operand, then the stages in order
+    auto opens = [](int s) { return ((s % 4) + 4) % 4 == 0; };
+    // after the last right-operand round of stage t - (depth - 1): the left pieces that stage still issued
+    int n = opens(slot - (depth - 1)) && rounds < 4 ? 4 - rounds : 0;
+    for (int d = depth - 2; d >= 1; --d) n += rounds + (opens(slot - d) ? 4 : 0);
+    if (slot == 0) {
+        // after the last left piece of stage t - 4: that stage's later right-operand rounds, then stages t - 3 .. t - 1
+        const int after_left = (rounds == 4 ? 1 : 0) + 3 * rounds;
+        if (after_left < n) n = after_left;
+    }
+    return n;
+}
+static_assert(skew_loads_in_flight(4, 3, 0, true) == 4 && skew_loads_in_flight(4, 3, 0, false) == 4 &&
+              skew_loads_in_flight(4, 3, 1, false) == 8 && skew_loads_in_flight(4, 3, 2, false) == 4 &&
+              skew_loads_in_flight(4, 3, 3, false) == 4, "the four-wave, three-buffer pipeline's counts");
+
+template <int RING, int SCALE, int WAVES = 4, int DEPTH = 3>
 __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
                                                  unsigned char *smem) {
-    constexpr int WAVES = 4;
+    static_assert((WAVES == 4 || WAVES == 8) && DEPTH >= 3 && DEPTH <= 5, "left operand: two super-stages of four stages");
     constexpr int kRows = 64 * WAVES;
     constexpr int kLhsRing = 2 * WAVES * 4096;
     constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
     constexpr int kNB = 8;
     constexpr int kPieces = 2 * kNB;
-    constexpr int kRounds = kPieces / WAVES;  // 4: one per MFMA group
+    constexpr int kRounds = kPieces / WAVES;  // four waves: 4, one per MFMA group
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -913,11 +935,11 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         lds_dma16(stage_src + piece * kFragBytes + lane * 16,
                   __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
     };
-    // portion q (0..3) of the loads of the stage-t epoch: right-operand round q of stage t + 2, and
-    // piece q of the next super-stage's left operand when t opens a super-stage
+    // portion q (0..3) of the loads of the stage-t epoch: piece q of the next super-stage's left operand when t
+    // opens a super-stage, and right-operand round q of stage t + DEPTH - 1 (into the buffer stage t - 1 has left)
     auto issue_portion = [&](int t, int buf, bool opens, int q) {
         if (opens) issue_lhs_piece((t >> 2) + 1, q);
-        issue_rhs_round(t + 2, buf == 0 ? 2 : buf - 1, q);
+        if (q < kRounds) issue_rhs_round(t + DEPTH - 1, buf == 0 ? DEPTH - 1 : buf - 1, q);
     };
     auto read_words = [&](int t, uint32_t (&wx)[4], uint32_t (&wy)[4]) {
         const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
@@ -965,13 +987,13 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
 #endif
     };
 
-    // prologue: left operand of super-stage 0, right operand of stages 0 and 1
+    // prologue: left operand of super-stage 0, right operand of stages 0 .. DEPTH - 2
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
 #pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(0, 0, j);
+    for (int st = 0; st < DEPTH - 1; ++st)
 #pragma unroll
-    for (int j = 0; j < kRounds; ++j) issue_rhs_round(1, 1, j);
+        for (int j = 0; j < kRounds; ++j) issue_rhs_round(st, st, j);
 
     v4i fa0[4], fa1[4], fbA[4], fbB[4];
     uint32_t wy[4] = {0u, 0u, 0u, 0u};  // the second words (MFMA step 1) of the current stage
@@ -985,7 +1007,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         constexpr bool kFirst = decltype(first_tag)::value;
         constexpr bool kActive = decltype(active_tag)::value;
         constexpr bool kHalf = decltype(half_tag)::value;
-        wait_vmcnt_then_barrier<kRounds + (kSlot == 1 ? 4 : 0)>();
+        wait_vmcnt_then_barrier<skew_loads_in_flight(kRounds, DEPTH, kSlot, kFirst)>();
         const bool opens = kSlot == 0;
         if constexpr (!kActive) {
 #pragma unroll
@@ -1037,7 +1059,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             __builtin_amdgcn_sched_barrier(0);
             // step 1, fragments 4..7 (fa1 x fbB) is left for the next stage's phase 0
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == DEPTH - 1 ? 0 : buf + 1;
     };
     // the last stage may be a half one; it is the only stage of a loop turn when stages = 1 mod 4 (slot 0)
     const bool half_last = p.k_words > 0 && p.k_words + 3 == p.e4 && stages > 4 && (stages & 3) == 1;
@@ -1119,6 +1141,25 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
         gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem);
     }
 }
+
+#ifdef GSW_EXP_WIDE8
+// Experiment (variant 12 of a -DGSW_EXP_WIDE8 library): the same pipeline with eight waves per workgroup, one
+// workgroup per CU: a 512-row tile shares every right-operand stage among eight waves (half the L2 -> LDS bytes
+// per MFMA) and the LDS that frees holds a deeper ring (GSW_EXP_WIDE8 = its depth, 3..5).
+template <int RING, int SCALE>
+__global__ __launch_bounds__(512, 1) void binlimb_gemm16_skew8(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                               int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b, nt, mt;
+    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
+    if (p.packed_tail && nt == nt_count - 1) {
+        if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 8, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem);
+        else gemm16_rowblock_body<RING, 8, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem);
+    } else {
+        gemm16_skew_body<RING, SCALE, 8, GSW_EXP_WIDE8>(p, ell, mask, b, nt, mt, smem);
+    }
+}
+#endif
 
 #ifdef GSW_EXP_PERSIST
 // Experiment (GSW_PERSIST=1 on a -DGSW_EXP_PERSIST library): a persistent, pass-synchronised grid.  512 workgroups, two
@@ -1333,7 +1374,7 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
         thread_local long cached_slots = -1;
         thread_local int cached_kind = -1, cached_wide = -1, cached_lean = 0;
         thread_local uint32_t cached_init[4];
-        if (a.scale_mode < 0 || a.scale_mode > 2 || (a.scale_mode && (ring.kind != kRingFp || variant != 9))) return hipErrorInvalidValue;
+        if (a.scale_mode < 0 || a.scale_mode > 2 || (a.scale_mode && (ring.kind != kRingFp || (variant != 9 && variant != 12)))) return hipErrorInvalidValue;
         // the limb sums' bound in units of one {0, 1} K slot (scaled bits weigh 2^c)
         const long k_slots = scale_units(a.e4, a.scale_mode);
         const char *env = getenv("GSW_FORCE_WIDE_COMBINE");
@@ -1395,6 +1436,24 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
         else
             hipLaunchKernelGGL((binlimb_gemm16_tall<kRingZpow2, 8>), grid, dim3(256), tall_lds_bytes<8>(), stream, a,
                                ring.ell, ring.mask, nt, mt);
+        return hipGetLastError();
+    }
+#endif
+#ifdef GSW_EXP_WIDE8
+    if (variant == 12) {
+        if (lean_used) *lean_used = a.lean_combine;
+        const int nt = col_tiles(a.out_cols), mt = (a.rows + 511) / 512;
+        const long blocks = (((long)a.batch + 7) / 8) * 8 * nt * mt;
+        if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
+        dim3 grid((unsigned)blocks);
+        constexpr int kLds = 2 * 8 * 4096 + (GSW_EXP_WIDE8 > 3 ? GSW_EXP_WIDE8 : 3) * kStageElems * 4 * kFragBytes;
+        const bool fp = ring.kind == kRingFp;
+#define GSW_LAUNCH8(R, S) hipLaunchKernelGGL((binlimb_gemm16_skew8<R, S>), grid, dim3(512), kLds, stream, a, ring.ell, ring.mask, nt, mt)
+        if (!fp) GSW_LAUNCH8(kRingZpow2, 0);
+        else if (a.scale_mode == 2) GSW_LAUNCH8(kRingFp, 2);
+        else if (a.scale_mode == 1) GSW_LAUNCH8(kRingFp, 1);
+        else GSW_LAUNCH8(kRingFp, 0);
+#undef GSW_LAUNCH8
         return hipGetLastError();
     }
 #endif
