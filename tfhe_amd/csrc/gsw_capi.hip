@@ -1761,11 +1761,11 @@ int gsw_diag_limb_start_values(int ring_kind, int bits, int k_slots, int wide, u
 }
 
 #ifdef GSW_EXP_TILE_CLOCK
-int gsw_diag_tile_clock(gsw_ctx *ctx, uint64_t *h_out8, int reset) {
-    if (!ctx || !h_out8) return fail(GSW_E_INVALID, "bad argument");
+int gsw_diag_tile_clock(gsw_ctx *ctx, uint64_t *h_out16, int reset) {
+    if (!ctx || !h_out16) return fail(GSW_E_INVALID, "bad argument");
     if (int rc = use_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(gswk::read_tile_clock((unsigned long long *)h_out8, reset != 0));
+    HIP_TRY(gswk::read_tile_clock((unsigned long long *)h_out16, reset != 0));
     return GSW_OK;
 }
 #endif

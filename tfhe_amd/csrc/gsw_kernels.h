@@ -129,7 +129,7 @@ int bit_scale_mode(const RingDesc &ring, int e4);
 long scale_units(int e4, int mode);
 
 #ifdef GSW_EXP_TILE_CLOCK
-hipError_t read_tile_clock(unsigned long long *out8, bool reset);
+hipError_t read_tile_clock(unsigned long long *out16, bool reset);
 #endif
 
 // output formats of the gadget decomposition (GSW_DECOMP_* of the C header)

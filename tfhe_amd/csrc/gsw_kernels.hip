@@ -694,7 +694,7 @@ constexpr int rowblock_lds_bytes() { return 2 * WAVES * 4096 + kPipeBuffers * kS
 // two fragments, 2 KiB apart in the prepared operand).
 template <int RING, int WAVES, int PACKED, int SCALE = 0>
 __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt,
-                                                     int mt, unsigned char *smem) {
+                                                     int mt, unsigned char *smem, int tid = (int)threadIdx.x) {
     constexpr int kRows = 64 * WAVES;
     constexpr int kLhsRing = 2 * WAVES * 4096;          // two super-stages of 64 B per row
     constexpr int kRhsStage = kStageElems * 4 * kFragBytes;
@@ -702,7 +702,6 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
     constexpr int kPieces = 2 * kNB;
     constexpr int kRounds = (kPieces + WAVES - 1) / WAVES;
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
@@ -884,9 +883,15 @@ static_assert(skew_loads_in_flight(4, 3, 0, true) == 4 && skew_loads_in_flight(4
               skew_loads_in_flight(4, 3, 1, false) == 8 && skew_loads_in_flight(4, 3, 2, false) == 4 &&
               skew_loads_in_flight(4, 3, 3, false) == 4, "the four-wave, three-buffer pipeline's counts");
 
-template <int RING, int SCALE, int WAVES = 4, int DEPTH = 3>
+// Where a tile body gets its next tile from.  NoTileStream: nowhere, the body computes the one tile it was given.
+struct NoTileStream {
+    static constexpr bool kOn = false;
+};
+
+template <int RING, int SCALE, int WAVES = 4, int DEPTH = 3, class STREAM = NoTileStream>
 __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uint32_t mask, int b, int nt, int mt,
-                                                 unsigned char *smem) {
+                                                 unsigned char *smem, int tid = (int)threadIdx.x,
+                                                 STREAM *stream = nullptr) {
     static_assert((WAVES == 4 || WAVES == 8) && DEPTH >= 3 && DEPTH <= 5, "left operand: two super-stages of four stages");
     constexpr int kRows = 64 * WAVES;
     constexpr int kLhsRing = 2 * WAVES * 4096;
@@ -895,27 +900,30 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     constexpr int kPieces = 2 * kNB;
     constexpr int kRounds = kPieces / WAVES;  // four waves: 4, one per MFMA group
 
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem);
 
-    const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
-    const uint8_t *rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
     const int stages = p.e4 / kStageElems;
-    const bool wave_active = mt * kRows + wave * 64 < p.rows;
-
     const int ld_r = lane >> 2, ld_j = (lane & 3) ^ ((ld_r >> 2) & 3);
+    // the tile at hand (a streaming body moves on to further tiles)
+    const uint8_t *rhs;
+    bool wave_active;
     const uint32_t *a_row[4];
+    auto set_tile = [&]() {
+        const uint32_t *lhs = p.lhs + (size_t)slot_of(p.lhs_slot, b) * p.lhs_stride;
+        rhs = p.rhs + slot_of(p.rhs_slot, b) * p.rhs_stride + (size_t)nt * p.e4 * (4 * kFragBytes);
+        wave_active = mt * kRows + wave * 64 < p.rows;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
-        if (row > p.rows - 1) row = p.rows - 1;
-        a_row[rg] = lhs + (size_t)row * p.ld_lhs;
-    }
+        for (int rg = 0; rg < 4; ++rg) {
+            int row = mt * kRows + wave * 64 + rg * 16 + ld_r;
+            if (row > p.rows - 1) row = p.rows - 1;
+            a_row[rg] = lhs + (size_t)row * p.ld_lhs;
+        }
+    };
+    set_tile();
 
     v4i acc[4][kNB];
-    init_acc16(acc, p, lane);
     const int r16 = lane & 15;
     const int sh = ((lane >> 4) & 1) * 4;
     const int swz = (r16 >> 2) & 3;
@@ -988,16 +996,19 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
     };
 
     // prologue: left operand of super-stage 0, right operand of stages 0 .. DEPTH - 2
+    auto issue_prologue = [&]() {
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
+        for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
 #pragma unroll
-    for (int st = 0; st < DEPTH - 1; ++st)
+        for (int st = 0; st < DEPTH - 1; ++st)
 #pragma unroll
-        for (int j = 0; j < kRounds; ++j) issue_rhs_round(st, st, j);
+            for (int j = 0; j < kRounds; ++j) issue_rhs_round(st, st, j);
+    };
+    issue_prologue();
 
     v4i fa0[4], fa1[4], fbA[4], fbB[4];
-    uint32_t wy[4] = {0u, 0u, 0u, 0u};  // the second words (MFMA step 1) of the current stage
-    int buf = 0;
+    uint32_t wy[4];  // the second words (MFMA step 1) of the current stage
+    int buf;
 
     // kHalf: the last stage of a K dimension whose last real word is the stage's first (n + 1 = 1 mod 4, as for
     // every n that is a multiple of 4): MFMA step 1 pairs the stage's words 1 and 3, which meet only zero digits,
@@ -1080,25 +1091,46 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         }
         if (half_last) stage(std::integral_constant<int, 0>{}, std::false_type{}, active_tag, stages - 1, std::true_type{});
     };
-    if (wave_active) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (wave_active) {
-        if (!half_last) mfma_group(fa1, fbB, 4);  // the last stage's deferred group
+    for (;;) {
+        init_acc16(acc, p, lane);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) wy[rg] = 0u;
+        buf = 0;
+        if (wave_active) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const TileCtx c{b, nt, mt, wave, lane, ell, mask};
-        gemm16_epilogue<RING, false>(p, c, kRows, acc);
+        const bool was_active = wave_active;
+        bool primed = false;
+        if constexpr (STREAM::kOn) {
+            // Every wave is past its last read of the tile's stages after the barrier in here; the next full tile's first
+            // loads go out before this tile's last MFMA group and epilogue, which cover their latency.
+            primed = stream->next_full_tile(smem, tid, b, nt, mt);
+            if (primed) {
+                set_tile();
+                issue_prologue();
+            }
+        }
+        if (was_active) {
+            if (!half_last) mfma_group(fa1, fbB, 4);  // the last stage's deferred group
+            gemm16_epilogue<RING, false>(p, c, kRows, acc);
+        }
+        if (!primed) return;
     }
 }
 
 #ifdef GSW_EXP_TILE_CLOCK
 // diagnostic build: shader-clock cycles and count of the workgroups of each kind
 // (0 full tile, 1 last column tile, 2 last row tile, 3 both)
-__device__ unsigned long long g_tile_clock[8];
-hipError_t read_tile_clock(unsigned long long *out8, bool reset) {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tile_clock), 64);
+// [8..10]: earliest start, latest end and the sum of the workgroups' durations on the constant-rate counter
+// (s_memrealtime): sum / (resident workgroups x (end - start)) is the share of the slots' time that was occupied
+__device__ unsigned long long g_tile_clock[16];
+hipError_t read_tile_clock(unsigned long long *out16, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tile_clock), 128);
     if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tile_clock), z, 64);
+        unsigned long long z[16] = {};
+        z[8] = ~0ull;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_tile_clock), z, 128);
     }
     return e;
 }
@@ -1112,13 +1144,17 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
 #ifdef GSW_EXP_TILE_CLOCK
     struct TileClock {
-        unsigned long long t0;
+        unsigned long long t0, r0;
         int kind;
-        __device__ TileClock(int k) : t0(__builtin_readcyclecounter()), kind(k) {}
+        __device__ TileClock(int k) : t0(__builtin_readcyclecounter()), r0(__builtin_amdgcn_s_memrealtime()), kind(k) {}
         __device__ ~TileClock() {
             if (threadIdx.x == 0) {
+                const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
                 atomicAdd(&g_tile_clock[2 * kind], __builtin_readcyclecounter() - t0);
                 atomicAdd(&g_tile_clock[2 * kind + 1], 1ull);
+                atomicMin(&g_tile_clock[8], r0);
+                atomicMax(&g_tile_clock[9], r1);
+                atomicAdd(&g_tile_clock[10], r1 - r0);
             }
         }
     } tile_clock((nt == nt_count - 1 ? 1 : 0) + (mt == mt_count - 1 ? 2 : 0));
@@ -1169,12 +1205,123 @@ __global__ __launch_bounds__(512, 1) void binlimb_gemm16_skew8(GemmArgs p, int e
 // others arrive (slots held by another kernel) goes on alone after a while.
 __device__ unsigned g_persist_count[8];
 
+// GSW_PERSIST=3: as 2, and a full tile's body goes straight on to the next full tile of the list: the next tile's number
+// is fetched a tile ahead (by thread 0, into a register), handed to the other waves through a word of LDS at the
+// barrier that ends a tile, and that tile's first loads are issued before the finished tile's epilogue.
+struct XcdTileStream {
+    static constexpr bool kOn = true;
+    unsigned *counter;  // this XCD's position in its list
+    int xcd, per_xcd, nt_count, mt_count;
+    const GemmArgs *args;
+    unsigned ahead;  // thread 0: the list index after `next`
+    int next;        // every thread: the list index to work on after the tile at hand
+
+    // a word of wave 0's private left-operand ring (second super-stage): dead between a tile's last stage and the
+    // next tile's first
+    static constexpr int kMailbox = 4 * 4096;
+
+    __device__ __forceinline__ void start(int tid, int slot) {
+        next = slot;  // the first 64 tiles of the list are handed out by workgroup number; the counter starts at 64
+        ahead = 0;
+        if (tid == 0) ahead = atomicAdd(counter, 1u);
+    }
+    // ends the tile at hand for the whole workgroup and moves `next` on; returns the index that was `next`
+    __device__ __forceinline__ int advance(unsigned char *smem, int tid) {
+        const int now = next;
+        volatile unsigned *box = reinterpret_cast<volatile unsigned *>(smem + kMailbox);
+        if (tid == 0) *box = ahead;
+        __syncthreads();
+        next = __builtin_amdgcn_readfirstlane((int)*box);
+        if (tid == 0 && next < per_xcd) ahead = atomicAdd(counter, 1u);
+        return now;
+    }
+    __device__ __forceinline__ bool decode(int index, int &b, int &nt, int &mt, bool &tail) const {
+        if (index >= per_xcd) return false;
+        if (!map_workgroup_blocked(args->batch, nt_count, mt_count, args->pass_rows, args->pass_cols, b, nt, mt, index * 8 + xcd))
+            return false;
+        tail = args->packed_tail && nt == nt_count - 1;
+        return true;
+    }
+    // called by a full tile's body after its last stage: true when the workgroup's next tile is a full tile too
+    // (b, nt, mt are then that tile's); otherwise they are left alone and the caller's loop takes over
+    __device__ __forceinline__ bool next_full_tile(unsigned char *smem, int tid, int &b, int &nt, int &mt) {
+        int nb, nnt, nmt;
+        bool tail;
+        if (!decode(next, nb, nnt, nmt, tail) || tail) {
+            __syncthreads();  // the barrier advance() would have been
+            return false;
+        }
+        advance(smem, tid);
+        b = nb, nt = nnt, mt = nmt;
+        return true;
+    }
+};
+
+// GSW_PERSIST=2: no rounds; a workgroup that has finished a tile takes the next one of its XCD's list from the
+// counter, as the hardware dispatcher would hand it to a fresh workgroup.
 template <int RING, int SCALE>
+__global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_streaming(GemmArgs p, int ell, uint32_t mask, int nt_count,
+                                                                        int mt_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    XcdTileStream ts;
+    ts.xcd = blockIdx.x & 7;
+    ts.counter = &g_persist_count[ts.xcd];
+    ts.per_xcd = ((p.batch + 7) / 8) * nt_count * mt_count;
+    ts.nt_count = nt_count, ts.mt_count = mt_count, ts.args = &p;
+    ts.start((int)threadIdx.x, (int)(blockIdx.x >> 3));
+    for (int turn = 0; turn <= ts.per_xcd; ++turn) {  // bounded: every turn takes at least one tile off the list
+        int b, nt, mt;
+        bool tail;
+        if (ts.next >= ts.per_xcd) break;
+        const bool valid = ts.decode(ts.next, b, nt, mt, tail);
+        ts.advance(smem, (int)threadIdx.x);  // the barrier in here also ends the tile before (LDS included)
+        if (!valid) continue;
+        int tid;  // new every turn: nothing lane-dependent of a tile body is hoisted out of the loop
+        asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
+        if (tail) {
+            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+        } else {
+            gemm16_skew_body<RING, SCALE, 4, 3, XcdTileStream>(p, ell, mask, b, nt, mt, smem, tid, &ts);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // thread 0's last fetch
+}
+
+template <int RING, int SCALE, bool DYNAMIC = false>
 __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_persistent(GemmArgs p, int ell, uint32_t mask, int nt_count,
                                                                          int mt_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per_xcd = ((p.batch + 7) / 8) * nt_count * mt_count;  // tiles in an XCD's list (some map to no entry)
+    if constexpr (DYNAMIC) {
+#ifdef GSW_EXP_PERSIST_DEPHASE
+        // the second workgroup of every CU (ids 256 apart) starts late by GSW_EXP_PERSIST_DEPHASE x 1024 cycles
+        if ((blockIdx.x >> 8) & 1)
+            for (int i = 0; i < GSW_EXP_PERSIST_DEPHASE; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
+        for (int turn = 0; turn < per_xcd; ++turn) {  // bounded: every turn takes a tile off the list
+            __syncthreads();  // the tile before is done with LDS
+            if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(smem) = atomicAdd(&g_persist_count[xcd], 1u);
+            __syncthreads();
+            const int local = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned *>(smem));
+            __syncthreads();
+            if (local >= per_xcd) return;
+            int b, nt, mt;
+            if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt, local * 8 + xcd)) continue;
+            // a thread number the compiler takes for new every turn: nothing lane-dependent of a tile body is hoisted
+            // out of the loop and kept in registers beside the other bodies (that spilled 18 registers)
+            int tid;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
+            if (p.packed_tail && nt == nt_count - 1) {
+                if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+                else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+            } else {
+                gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+            }
+        }
+        return;
+    }
     const int rounds = (per_xcd + 63) / 64;
     for (int r = 0; r < rounds; ++r) {
         if (r > 0) {
@@ -1193,11 +1340,13 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_persistent(GemmArg
         const int local = r * 64 + slot;
         if (local >= per_xcd || !map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt, local * 8 + xcd))
             continue;
+        int tid;  // new every round, as above
+        asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
         if (p.packed_tail && nt == nt_count - 1) {
-            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem);
-            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem);
+            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
+            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
         } else {
-            gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem);
+            gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
         }
     }
 }
@@ -1516,13 +1665,27 @@ hipError_t launch_gemm(const RingDesc &ring, const GemmArgs &args, int variant, 
 #endif
         default: {
 #ifdef GSW_EXP_PERSIST
-            if (const char *e = getenv("GSW_PERSIST"); e && e[0] == '1') {
+            if (const char *e = getenv("GSW_PERSIST"); e && (e[0] == '1' || e[0] == '2' || e[0] == '3')) {
                 void *cnt = nullptr;
                 hipError_t pe = hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_persist_count));
-                if (pe == hipSuccess) pe = hipMemsetAsync(cnt, 0, sizeof(unsigned) * 8, stream);
+                if (pe == hipSuccess) pe = hipMemsetD32Async((hipDeviceptr_t)cnt, e[0] == '3' ? 64 : 0, 8, stream);
                 if (pe != hipSuccess) return pe;
                 grid = dim3(512);
                 constexpr int kLds = rowblock_lds_bytes<4>();
+                if (e[0] == '3') {
+                    if (!fp) GSW_LAUNCH((binlimb_gemm16_skew_streaming<kRingZpow2, 0>), 256, kLds);
+                    else if (a.scale_mode == 2) GSW_LAUNCH((binlimb_gemm16_skew_streaming<kRingFp, 2>), 256, kLds);
+                    else if (a.scale_mode == 1) GSW_LAUNCH((binlimb_gemm16_skew_streaming<kRingFp, 1>), 256, kLds);
+                    else return hipErrorInvalidValue;
+                    break;
+                }
+                if (e[0] == '2') {
+                    if (!fp) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingZpow2, 0, true>), 256, kLds);
+                    else if (a.scale_mode == 2) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 2, true>), 256, kLds);
+                    else if (a.scale_mode == 1) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 1, true>), 256, kLds);
+                    else return hipErrorInvalidValue;
+                    break;
+                }
                 if (!fp) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingZpow2, 0>), 256, kLds);
                 else if (a.scale_mode == 2) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 2>), 256, kLds);
                 else if (a.scale_mode == 1) GSW_LAUNCH((binlimb_gemm16_skew_persistent<kRingFp, 1>), 256, kLds);

@@ -28,14 +28,22 @@ _lib.check(L.gsw_fill_uniform(eng.handle, 5, 1, 0, ring.max_u64(), 1, pool.ptr, 
 prep = eng.alloc(eng.prepared_bytes * args.batch)
 out = tfhe_amd.Ciphertext(eng, args.batch)
 _lib.check(L.gsw_prepare_rhs(eng.handle, pool.entry_ptr(args.batch), ct, prep.ptr, args.batch))
-res = (C.c_uint64 * 8)()
+res = (C.c_uint64 * 16)()
+_lib.check(L.gsw_diag_tile_clock(eng.handle, res, 1))  # reset (earliest start = max)
+import time  # noqa: E402
 for rep in range(3):
+    t0 = time.perf_counter()
     _lib.check(L.gsw_mul_gadget_prepared(eng.handle, pool.ptr, ct, prep.ptr, eng.prepared_bytes, out.ptr, ct, args.batch, 0))
-    _lib.check(L.gsw_diag_tile_clock(eng.handle, res, 1))
+    _lib.check(L.gsw_diag_tile_clock(eng.handle, res, 1))  # waits for the stream
+    wall_us = (time.perf_counter() - t0) * 1e6
 names = ["full tile", "last column tile", "last row tile", "last row + last column"]
 base = res[0] / max(res[1], 1)
 for k in range(4):
     if res[2 * k + 1]:
         mean = res[2 * k] / res[2 * k + 1]
         print(f"{names[k]:26s} {res[2 * k + 1]:8d} workgroups, mean {mean:10.0f} cycles = {mean / base:5.2f} full tiles, "
-              f"share of workgroup time {res[2 * k] / sum(res[0::2]):6.3f}")
+              f"share of workgroup time {res[2 * k] / sum(res[0:8:2]):6.3f}")
+span = res[9] - res[8]
+slots = 512  # 256 CUs x 2 resident workgroups
+print(f"host wall time of the call {wall_us:.1f} us; launch span {span / 100:.1f} us (100 MHz counter), workgroup time {res[10] / 100:.1f} us over {slots} slots: "
+      f"occupied share {res[10] / (slots * span):.4f}")
