@@ -426,6 +426,24 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, uint32_t lds_wave_ba
         : "memory");
 }
 
+// The same load with the address as a uniform base (scalar registers) + a per-lane byte offset + a constant:
+// no vector instruction is spent on the address.  The constant moves the LDS side as well: lane i's 16 bytes
+// land at M0 + IMM + 16 i.
+template <int IMM>
+__device__ __forceinline__ void lds_dma16_base(const void *uniform_base, uint32_t lane_offset, uint32_t lds_wave_base) {
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed instruction offset");
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_offset), "s"(uniform_base), "s"(lds_wave_base), "n"(IMM)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -677,9 +695,9 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmArgs &p, const TileCtx
 // fused into ds_read2st64_b64, which is serviced in groups of 16 lanes with 32 banks (8 LDS cycles,
 // and 2-way conflicts on the left-operand image) where ds_read_b64 takes 2 cycles conflict free.
 __device__ __forceinline__ uint2 lds_read_b64_alone(uint32_t lds_byte_address) {
-    asm volatile("" : "+v"(lds_byte_address));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const u32x2 *>((uintptr_t)lds_byte_address);
+    // volatile: never merged with a neighbour, and a constant part of the address still goes into the offset field
+    const u32x2 v = *reinterpret_cast<__attribute__((address_space(3))) const volatile u32x2 *>((uintptr_t)lds_byte_address);
     return make_uint2(v.x, v.y);
 }
 
@@ -738,13 +756,17 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(super_stage, rg);
     };
+    const uint32_t rhs_lane_offset = (uint32_t)((wave % kPieces) * kFragBytes + lane * 16);
     auto issue_rhs_round = [&](int t, int buf, int j) {
         if (t > stages - 1) t = stages - 1;
         const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
         const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
         const int piece = (j * WAVES + wave) % kPieces;
-        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+        if constexpr (kRounds == 1)  // the packed tiles: a uniform base and one per-lane offset, no address arithmetic
+            lds_dma16_base<0>(stage_src, rhs_lane_offset, __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+        else
+            lds_dma16(stage_src + piece * kFragBytes + lane * 16,
+                      __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
     };
     auto issue_rhs = [&](int t, int buf) {
 #pragma unroll
@@ -935,19 +957,23 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
         lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
     };
-    auto issue_rhs_round = [&](int t, int buf, int j) {
+    // a wave loads pieces wave * kRounds .. + kRounds - 1 of a stage: one per-lane offset for all of them, the piece
+    // within the wave's share is the instruction's constant offset
+    const uint32_t rhs_lane_offset = (uint32_t)(wave * kRounds * kFragBytes + lane * 16);
+    auto issue_rhs_round = [&](int t, int buf, auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
         if (t > stages - 1) t = stages - 1;
         const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
         const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        const int piece = (j * WAVES + wave) % kPieces;
-        lds_dma16(stage_src + piece * kFragBytes + lane * 16,
-                  __builtin_amdgcn_readfirstlane(base + (uint32_t)(piece * kFragBytes)));
+        lds_dma16_base<j * kFragBytes>(stage_src, rhs_lane_offset,
+                                       __builtin_amdgcn_readfirstlane(base + (uint32_t)(wave * kRounds * kFragBytes)));
     };
     // portion q (0..3) of the loads of the stage-t epoch: piece q of the next super-stage's left operand when t
     // opens a super-stage, and right-operand round q of stage t + DEPTH - 1 (into the buffer stage t - 1 has left)
-    auto issue_portion = [&](int t, int buf, bool opens, int q) {
+    auto issue_portion = [&](int t, int buf, bool opens, auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
         if (opens) issue_lhs_piece((t >> 2) + 1, q);
-        if (q < kRounds) issue_rhs_round(t + DEPTH - 1, buf == 0 ? DEPTH - 1 : buf - 1, q);
+        if constexpr (q < kRounds) issue_rhs_round(t + DEPTH - 1, buf == 0 ? DEPTH - 1 : buf - 1, q_tag);
     };
     auto read_words = [&](int t, uint32_t (&wx)[4], uint32_t (&wy)[4]) {
         const uint32_t sa = lds0 + (uint32_t)(((t >> 2) & 1) * (WAVES * 4096) + wave * 4096 + r16 * 64 +
@@ -1000,9 +1026,14 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) issue_lhs_piece(0, rg);
 #pragma unroll
-        for (int st = 0; st < DEPTH - 1; ++st)
-#pragma unroll
-            for (int j = 0; j < kRounds; ++j) issue_rhs_round(st, st, j);
+        for (int st = 0; st < DEPTH - 1; ++st) {
+            issue_rhs_round(st, st, std::integral_constant<int, 0>{});
+            issue_rhs_round(st, st, std::integral_constant<int, 1>{});
+            if constexpr (kRounds == 4) {
+                issue_rhs_round(st, st, std::integral_constant<int, 2>{});
+                issue_rhs_round(st, st, std::integral_constant<int, 3>{});
+            }
+        }
     };
     issue_prologue();
 
@@ -1021,8 +1052,10 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         wait_vmcnt_then_barrier<skew_loads_in_flight(kRounds, DEPTH, kSlot, kFirst)>();
         const bool opens = kSlot == 0;
         if constexpr (!kActive) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) issue_portion(t, buf, opens, q);
+            issue_portion(t, buf, opens, std::integral_constant<int, 0>{});
+            issue_portion(t, buf, opens, std::integral_constant<int, 1>{});
+            issue_portion(t, buf, opens, std::integral_constant<int, 2>{});
+            issue_portion(t, buf, opens, std::integral_constant<int, 3>{});
         } else {
             if constexpr (kFirst) {
                 uint32_t wx[4];
@@ -1031,7 +1064,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             }
             // phase 0: first fragments of this stage; the previous stage's last group covers their latency
             read_frags(fbA, buf, 0);
-            issue_portion(t, buf, opens, 0);
+            issue_portion(t, buf, opens, std::integral_constant<int, 0>{});
             if constexpr (!kFirst) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(fa1, fbB, 4);
@@ -1039,7 +1072,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             __builtin_amdgcn_sched_barrier(0);
             // phase 1: step 0, fragments 0..3; the step-1 fragments of this stage are expanded meanwhile
             read_frags(fbB, buf, 1);
-            issue_portion(t, buf, opens, 1);
+            issue_portion(t, buf, opens, std::integral_constant<int, 1>{});
             mfma_group(fa0, fbA, 0);
             if constexpr (!kHalf) {
                 expand(fa1, wy);
@@ -1049,17 +1082,17 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: step 0, fragments 4..7; the next stage's left-operand words are fetched
             if constexpr (!kHalf) read_frags(fbA, buf, 2);
-            issue_portion(t, buf, opens, 2);
+            issue_portion(t, buf, opens, std::integral_constant<int, 2>{});
             mfma_group(fa0, fbB, 4);
             if constexpr (kHalf) {
-                issue_portion(t, buf, opens, 3);  // the counted waits of the loads stay as they are
+                issue_portion(t, buf, opens, std::integral_constant<int, 3>{});  // the counted waits of the loads stay as they are
             } else {
                 uint32_t nx[4], ny[4];
                 read_words(t + 1, nx, ny);
                 __builtin_amdgcn_sched_barrier(0);
                 // phase 3: step 1, fragments 0..3; the next stage's step-0 fragments are expanded
                 read_frags(fbB, buf, 3);
-                issue_portion(t, buf, opens, 3);
+                issue_portion(t, buf, opens, std::integral_constant<int, 3>{});
                 mfma_group(fa1, fbA, 0);
                 expand(fa0, nx);
                 pin(fa0);
