@@ -10,7 +10,8 @@ SOURCES = [os.path.join(HERE, "csrc", "gsw_kernels.hip"), os.path.join(HERE, "cs
 HEADERS = [os.path.join(HERE, "csrc", "gsw_kernels.h"), os.path.join(HERE, "csrc", "gsw_wire.h"),
            os.path.join(HERE, "..", "include", "gsw_hip.h")]
 # -DGSW_DIAGNOSTIC_BUILDS additionally compiles csrc/gsw_kernels_diag.inc (superseded kernels, for A/B timing),
-# -DGSW_EXP_TALL csrc/gsw_kernels_tall.inc (the tall-tile experiment)
+# -DGSW_EXP_TALL csrc/gsw_kernels_tall.inc (the tall-tile experiment), -DGSW_EXP_WIDE8=<depth> / -DGSW_EXP_PERSIST
+# csrc/gsw_kernels_exp.inc (eight-wave tiles, persistent grids); the shipped library holds none of them
 OUT = os.path.join(HERE, "libgsw_hip.so")
 
 

@@ -1211,178 +1211,8 @@ __global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew(GemmArgs p, int el
     }
 }
 
-#ifdef GSW_EXP_WIDE8
-// Experiment (variant 12 of a -DGSW_EXP_WIDE8 library): the same pipeline with eight waves per workgroup, one
-// workgroup per CU: a 512-row tile shares every right-operand stage among eight waves (half the L2 -> LDS bytes
-// per MFMA) and the LDS that frees holds a deeper ring (GSW_EXP_WIDE8 = its depth, 3..5).
-template <int RING, int SCALE>
-__global__ __launch_bounds__(512, 1) void binlimb_gemm16_skew8(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                               int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int b, nt, mt;
-    if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt)) return;
-    if (p.packed_tail && nt == nt_count - 1) {
-        if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 8, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem);
-        else gemm16_rowblock_body<RING, 8, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem);
-    } else {
-        gemm16_skew_body<RING, SCALE, 8, GSW_EXP_WIDE8>(p, ell, mask, b, nt, mt, smem);
-    }
-}
-#endif
-
-#ifdef GSW_EXP_PERSIST
-// Experiment (GSW_PERSIST=1 on a -DGSW_EXP_PERSIST library): a persistent, pass-synchronised grid.  512 workgroups, two
-// per CU, stay resident; the 64 of an XCD walk that XCD's tile list (the order of map_workgroup_blocked) in rounds of
-// 64 consecutive tiles and meet at a counter before every round, so that the tiles that share operand panels
-// start together and stream them through the L2 in step.  The wait is bounded: a workgroup that does not see the
-// others arrive (slots held by another kernel) goes on alone after a while.
-__device__ unsigned g_persist_count[8];
-
-// GSW_PERSIST=3: as 2, and a full tile's body goes straight on to the next full tile of the list: the next tile's number
-// is fetched a tile ahead (by thread 0, into a register), handed to the other waves through a word of LDS at the
-// barrier that ends a tile, and that tile's first loads are issued before the finished tile's epilogue.
-struct XcdTileStream {
-    static constexpr bool kOn = true;
-    unsigned *counter;  // this XCD's position in its list
-    int xcd, per_xcd, nt_count, mt_count;
-    const GemmArgs *args;
-    unsigned ahead;  // thread 0: the list index after `next`
-    int next;        // every thread: the list index to work on after the tile at hand
-
-    // a word of wave 0's private left-operand ring (second super-stage): dead between a tile's last stage and the
-    // next tile's first
-    static constexpr int kMailbox = 4 * 4096;
-
-    __device__ __forceinline__ void start(int tid, int slot) {
-        next = slot;  // the first 64 tiles of the list are handed out by workgroup number; the counter starts at 64
-        ahead = 0;
-        if (tid == 0) ahead = atomicAdd(counter, 1u);
-    }
-    // ends the tile at hand for the whole workgroup and moves `next` on; returns the index that was `next`
-    __device__ __forceinline__ int advance(unsigned char *smem, int tid) {
-        const int now = next;
-        volatile unsigned *box = reinterpret_cast<volatile unsigned *>(smem + kMailbox);
-        if (tid == 0) *box = ahead;
-        __syncthreads();
-        next = __builtin_amdgcn_readfirstlane((int)*box);
-        if (tid == 0 && next < per_xcd) ahead = atomicAdd(counter, 1u);
-        return now;
-    }
-    __device__ __forceinline__ bool decode(int index, int &b, int &nt, int &mt, bool &tail) const {
-        if (index >= per_xcd) return false;
-        if (!map_workgroup_blocked(args->batch, nt_count, mt_count, args->pass_rows, args->pass_cols, b, nt, mt, index * 8 + xcd))
-            return false;
-        tail = args->packed_tail && nt == nt_count - 1;
-        return true;
-    }
-    // called by a full tile's body after its last stage: true when the workgroup's next tile is a full tile too
-    // (b, nt, mt are then that tile's); otherwise they are left alone and the caller's loop takes over
-    __device__ __forceinline__ bool next_full_tile(unsigned char *smem, int tid, int &b, int &nt, int &mt) {
-        int nb, nnt, nmt;
-        bool tail;
-        if (!decode(next, nb, nnt, nmt, tail) || tail) {
-            __syncthreads();  // the barrier advance() would have been
-            return false;
-        }
-        advance(smem, tid);
-        b = nb, nt = nnt, mt = nmt;
-        return true;
-    }
-};
-
-// GSW_PERSIST=2: no rounds; a workgroup that has finished a tile takes the next one of its XCD's list from the
-// counter, as the hardware dispatcher would hand it to a fresh workgroup.
-template <int RING, int SCALE>
-__global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_streaming(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                                        int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    XcdTileStream ts;
-    ts.xcd = blockIdx.x & 7;
-    ts.counter = &g_persist_count[ts.xcd];
-    ts.per_xcd = ((p.batch + 7) / 8) * nt_count * mt_count;
-    ts.nt_count = nt_count, ts.mt_count = mt_count, ts.args = &p;
-    ts.start((int)threadIdx.x, (int)(blockIdx.x >> 3));
-    for (int turn = 0; turn <= ts.per_xcd; ++turn) {  // bounded: every turn takes at least one tile off the list
-        int b, nt, mt;
-        bool tail;
-        if (ts.next >= ts.per_xcd) break;
-        const bool valid = ts.decode(ts.next, b, nt, mt, tail);
-        ts.advance(smem, (int)threadIdx.x);  // the barrier in here also ends the tile before (LDS included)
-        if (!valid) continue;
-        int tid;  // new every turn: nothing lane-dependent of a tile body is hoisted out of the loop
-        asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
-        if (tail) {
-            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-        } else {
-            gemm16_skew_body<RING, SCALE, 4, 3, XcdTileStream>(p, ell, mask, b, nt, mt, smem, tid, &ts);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // thread 0's last fetch
-}
-
-template <int RING, int SCALE, bool DYNAMIC = false>
-__global__ __launch_bounds__(256, 2) void binlimb_gemm16_skew_persistent(GemmArgs p, int ell, uint32_t mask, int nt_count,
-                                                                         int mt_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_xcd = ((p.batch + 7) / 8) * nt_count * mt_count;  // tiles in an XCD's list (some map to no entry)
-    if constexpr (DYNAMIC) {
-#ifdef GSW_EXP_PERSIST_DEPHASE
-        // the second workgroup of every CU (ids 256 apart) starts late by GSW_EXP_PERSIST_DEPHASE x 1024 cycles
-        if ((blockIdx.x >> 8) & 1)
-            for (int i = 0; i < GSW_EXP_PERSIST_DEPHASE; ++i) __builtin_amdgcn_s_sleep(16);
-#endif
-        for (int turn = 0; turn < per_xcd; ++turn) {  // bounded: every turn takes a tile off the list
-            __syncthreads();  // the tile before is done with LDS
-            if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(smem) = atomicAdd(&g_persist_count[xcd], 1u);
-            __syncthreads();
-            const int local = __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned *>(smem));
-            __syncthreads();
-            if (local >= per_xcd) return;
-            int b, nt, mt;
-            if (!map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt, local * 8 + xcd)) continue;
-            // a thread number the compiler takes for new every turn: nothing lane-dependent of a tile body is hoisted
-            // out of the loop and kept in registers beside the other bodies (that spilled 18 registers)
-            int tid;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
-            if (p.packed_tail && nt == nt_count - 1) {
-                if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-                else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-            } else {
-                gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-            }
-        }
-        return;
-    }
-    const int rounds = (per_xcd + 63) / 64;
-    for (int r = 0; r < rounds; ++r) {
-        if (r > 0) {
-            __syncthreads();  // this workgroup is done with its tile of the round before (LDS included)
-            if (threadIdx.x == 0) {
-                atomicAdd(&g_persist_count[xcd], 1u);
-                const unsigned target = 64u * (unsigned)r;
-                for (int spins = 0; spins < 4000; ++spins) {
-                    if (__hip_atomic_load(&g_persist_count[xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-            __syncthreads();
-        }
-        int b, nt, mt;
-        const int local = r * 64 + slot;
-        if (local >= per_xcd || !map_workgroup_blocked(p.batch, nt_count, mt_count, p.pass_rows, p.pass_cols, b, nt, mt, local * 8 + xcd))
-            continue;
-        int tid;  // new every round, as above
-        asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"((int)threadIdx.x));
-        if (p.packed_tail && nt == nt_count - 1) {
-            if (p.packed_tail == kTailNarrow) gemm16_rowblock_body<RING, 4, kTailNarrow, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-            else gemm16_rowblock_body<RING, 4, kTailPacked, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-        } else {
-            gemm16_skew_body<RING, SCALE>(p, ell, mask, b, nt, mt, smem, tid);
-        }
-    }
-}
+#if defined(GSW_EXP_WIDE8) || defined(GSW_EXP_PERSIST)
+#include "gsw_kernels_exp.inc"
 #endif
 
 // Superseded contraction kernels (variants 0, 1, 4..8) and timing-only ablation builds: compiled only into
