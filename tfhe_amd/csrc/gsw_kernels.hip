@@ -449,6 +449,17 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// The same for a body that carries LDS reads across the barrier (the skewed pipeline reads the fragments of a stage's
+// last MFMA group at the end of the stage and uses them after the next barrier): the wave's own LDS reads have to
+// have returned before it arrives, because right behind the barrier the other waves re-load that buffer and nothing
+// orders an LDS-DMA write behind a ds_read that is still queued.  Without the lgkmcnt(0) an L2-warm load (a few
+// hundred cycles from issue to landing) overtook a queued read about once in 10^5 stages at n = 10 and 10^9 at
+// n = 256: one wrong product in ten to fifty thousand, seen only as digests that differ between identical runs.
+template <int N>
+__device__ __forceinline__ void wait_loads_and_own_reads_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 constexpr int kPipeBuffers = 3;
 template <int WAVES>
 constexpr int pipe_lds_bytes() { return kPipeBuffers * (WAVES * 1024 + kStageElems * 4 * kFragBytes); }
@@ -957,16 +968,20 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         const uint32_t base = lds0 + (uint32_t)((super_stage & 1) * (WAVES * 4096) + wave * 4096);
         lds_dma16(a_row[rg] + st * kStageElems, __builtin_amdgcn_readfirstlane(base + (uint32_t)(rg * 1024)));
     };
-    // a wave loads pieces wave * kRounds .. + kRounds - 1 of a stage: one per-lane offset for all of them, the piece
-    // within the wave's share is the instruction's constant offset
-    const uint32_t rhs_lane_offset = (uint32_t)(wave * kRounds * kFragBytes + lane * 16);
+    // Round j of a stage: the waves load pieces j * WAVES .. + WAVES - 1, wave w the piece j * WAVES + w, so that the
+    // rounds bring the fragments in the order the MFMA groups read them: the round that lands last -- its count may
+    // have left vmcnt only just before the stage's barrier -- holds the fragments read last, a thousand cycles later.
+    // (Handing every wave four consecutive pieces instead, with the round in the instruction's constant, reads a
+    // just-landed piece right after the barrier, and one product in 10^4 came out wrong.)
+    // The address is a uniform base (scalar arithmetic) plus one per-lane offset: no vector instruction spent on it.
+    const uint32_t rhs_lane_offset = (uint32_t)(wave * kFragBytes + lane * 16);
     auto issue_rhs_round = [&](int t, int buf, auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         if (t > stages - 1) t = stages - 1;
         const uint32_t base = lds0 + (uint32_t)(kLhsRing + buf * kRhsStage);
-        const uint8_t *stage_src = rhs + (size_t)t * (kPieces * kFragBytes);
-        lds_dma16_base<j * kFragBytes>(stage_src, rhs_lane_offset,
-                                       __builtin_amdgcn_readfirstlane(base + (uint32_t)(wave * kRounds * kFragBytes)));
+        const uint8_t *round_src = rhs + (size_t)t * (kPieces * kFragBytes) + j * WAVES * kFragBytes;
+        lds_dma16_base<0>(round_src, rhs_lane_offset,
+                          __builtin_amdgcn_readfirstlane(base + (uint32_t)((j * WAVES + wave) * kFragBytes)));
     };
     // portion q (0..3) of the loads of the stage-t epoch: piece q of the next super-stage's left operand when t
     // opens a super-stage, and right-operand round q of stage t + DEPTH - 1 (into the buffer stage t - 1 has left)
@@ -1049,7 +1064,7 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         constexpr bool kFirst = decltype(first_tag)::value;
         constexpr bool kActive = decltype(active_tag)::value;
         constexpr bool kHalf = decltype(half_tag)::value;
-        wait_vmcnt_then_barrier<skew_loads_in_flight(kRounds, DEPTH, kSlot, kFirst)>();
+        wait_loads_and_own_reads_then_barrier<skew_loads_in_flight(kRounds, DEPTH, kSlot, kFirst)>();
         const bool opens = kSlot == 0;
         if constexpr (!kActive) {
             issue_portion(t, buf, opens, std::integral_constant<int, 0>{});

@@ -32,6 +32,7 @@ def main():
     torch.cuda.synchronize()
     _lib.check(L.gsw_ctx_set_workspace_limit(eng.handle, batch * eng.prepared_bytes))
     first = None
+    failures = 0
     for rep in range(repeats):
         flags = rep & 1  # alternate mult / nand so that consecutive runs differ in the epilogue
         _lib.check(L.gsw_mul_gadget_batch_digest(eng.handle, pool.data_ptr(), 2 * ct, pool.data_ptr() + 4 * ct, 2 * ct,
@@ -46,9 +47,17 @@ def main():
         if rep < 2:
             first = (first or {})
             first[flags] = d
-        else:
-            assert np.array_equal(d, first[flags]), f"run {rep}: digests changed between identical runs"
+        elif not np.array_equal(d, first[flags]):
+            bad = np.nonzero(d != first[flags])[0]
+            msg = f"run {rep}: digests of {len(bad)} of {batch} products changed between identical runs, first entries {bad[:8].tolist()}"
+            if not os.environ.get("SOAK_KEEP_GOING"):
+                raise AssertionError(msg)
+            print(msg, flush=True)
+            failures += 1
+            continue
         print(f"run {rep} ok", flush=True)
+    if failures:
+        raise SystemExit(f"soak FAILED: {failures} of {repeats} runs differ")
     print(f"soak ok: {ring_name} n={n} batch={batch} x{repeats}")
 
 
