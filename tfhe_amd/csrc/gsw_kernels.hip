@@ -452,9 +452,11 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
 // The same for a body that carries LDS reads across the barrier (the skewed pipeline reads the fragments of a stage's
 // last MFMA group at the end of the stage and uses them after the next barrier): the wave's own LDS reads have to
 // have returned before it arrives, because right behind the barrier the other waves re-load that buffer and nothing
-// orders an LDS-DMA write behind a ds_read that is still queued.  Without the lgkmcnt(0) an L2-warm load (a few
-// hundred cycles from issue to landing) overtook a queued read about once in 10^5 stages at n = 10 and 10^9 at
-// n = 256: one wrong product in ten to fifty thousand, seen only as digests that differ between identical runs.
+// orders an LDS-DMA write behind a ds_read that is still queued.  The waves of a thin row tile that own no rows are
+// the ones that do it: they issue all their loads of a stage in one burst right behind the barrier, the pieces of
+// the last group among them.  Without the lgkmcnt(0) an L2-warm load (a few hundred cycles from issue to landing)
+// overtook a queued read about once in 10^5 stages at n = 10 and 10^9 at n = 256: one wrong product in ten to fifty
+// thousand, seen only as digests that differ between identical runs.
 template <int N>
 __device__ __forceinline__ void wait_loads_and_own_reads_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
