@@ -54,3 +54,37 @@ def test_repeated_batches_give_identical_digests(ring_name, n, batch, repeats):
         assert len(bad) == 0, (f"run {rep}: {len(bad)} of {batch} products differ from the first run of the same batch "
                                f"(entries {bad[:8].tolist()})")
     assert len(set(first[0].tolist())) == batch  # digests tell the products apart
+
+
+@pytest.mark.parametrize("ring_name", ["fp", "z32"])
+def test_repeated_dense_products_and_encryptions_are_identical(ring_name):
+    """The same check on the other users of the contraction kernel: the reference-format N x N product (flattened left
+    operand: slabs of one product as batch entries; arbitrary left operand: digit x digit products) and encryption
+    with given random bits (K = m), small shapes whose operands stay in L2, many repeats."""
+    import tfhe_amd
+
+    ring = tfhe_amd.Fp() if ring_name == "fp" else tfhe_amd.Zpow2(32)
+    n = 10
+    gsw = tfhe_amd.GSW(ring, n, n * ring.ell, seed=5, check_max=False)  # Z/2^32: the reference's keygen panics (max <= P)
+    big_n = gsw.engine.big_n
+    rng = np.random.default_rng(21)
+    a = rng.integers(0, ring.q, size=(big_n, big_n), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, ring.q, size=(big_n, big_n), dtype=np.uint64).astype(np.uint32)
+    flat = gsw.flatten_matrix(a)  # a {0, 1} matrix: takes the binary x digit contraction
+    gsw.set_dense_fast(2)  # the MFMA paths at any size
+    for left, path, what in ((flat, 1, "flattened left operand"), (a, 2, "arbitrary left operand")):
+        first = gsw.mult_dense(left, b)
+        assert gsw.last_dense_path() == path, what
+        for rep in range(20):
+            again = gsw.mult_dense(left, b)
+            bad = np.argwhere(again != first)
+            assert len(bad) == 0, f"{what}, run {rep}: {len(bad)} entries differ from the first run, first at {bad[0].tolist()}"
+    _, pk = gsw.keygen()
+    batch = 32
+    rbits = rng.integers(0, 2, size=(batch, big_n, n * ring.ell), dtype=np.uint8)
+    msgs = [int(v) for v in rng.integers(0, 2, size=batch)]
+    first = gsw.encrypt_batch(pk, msgs, rbits=rbits).to_compact()
+    for rep in range(20):
+        again = gsw.encrypt_batch(pk, msgs, rbits=rbits).to_compact()
+        bad = np.argwhere(again != first)
+        assert len(bad) == 0, f"encrypt_batch, run {rep}: {len(bad)} entries differ from the first run, first at {bad[0].tolist()}"
