@@ -849,9 +849,11 @@ __device__ __forceinline__ void gemm16_rowblock_body(const GemmArgs &p, int ell,
 #pragma unroll
                 for (int j = 0; j < kGroup; ++j) {
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
+                    for (int k = 0; k < 4; ++k) {
+                        const int rg = (j & 1) ? 3 - k : k;  // back and forth: one operand changes between neighbours
                         acc[rg][f0 + j] =
                             __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[cur][j], acc[rg][f0 + j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1017,11 +1019,16 @@ __device__ __forceinline__ void gemm16_skew_body(const GemmArgs &p, int ell, uin
         for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const v4i *>(sb + j * kFragBytes);
     };
     auto mfma_group = [&](const v4i (&fa)[4], const v4i (&fb)[4], int f0) {
+        // Four MFMAs share a right fragment (the operand with the random bytes), and the row groups go back and forth
+        // so that only one operand changes from one MFMA to the next: the chip is power-limited, and this order is
+        // 0.6-0.9 % faster than the plain nested loops, 1.5-1.8 % faster than four MFMAs sharing the left fragment.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
+            for (int k = 0; k < 4; ++k) {
+                const int rg = (j & 1) ? 3 - k : k;
                 acc[rg][f0 + j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[rg], fb[j], acc[rg][f0 + j], 0, 0, 0);
+            }
         }
     };
     // 16 MFMAs with V vector ALU instructions after each of them (scheduler directive, no code)
