@@ -980,3 +980,44 @@ def test_n1024_takes_the_64_bit_recombination_natively(oracle, tfhe_amd):
     for r in rows:
         _assert_equal(got[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1), f"row {r} vs oracle")
         _assert_equal(got_nand[r:r + 1], og.mul_gadget_rows(c1, c2, int(r), 1, flags=oracle.FLAG_NAND), f"nand row {r} vs oracle")
+
+
+@pytest.mark.parametrize("n,mode", [(271, 2), (272, 1), (679, 1), (680, 0)])
+def test_extreme_operands_at_the_ends_of_the_scaling_modes(oracle, tfhe_amd, n, mode):
+    """The largest contractions each way of weighting the left operand's bits still takes with the 32-bit
+    recombination (bits weighing 2^(k & 3) up to 272 words of K, 2^(k & 1) up to 680, plain beyond), with the operands
+    that drive the limb sums to both ends of their range: left operands of all ones, right operands whose digits are
+    all -128 or all +127 before and after the scaling.  Sampled rows, mult and nand, against the oracle."""
+    from tfhe_amd import _lib
+
+    ring_o, ring_d = _rings(oracle, tfhe_amd)["fp"]
+    gsw = tfhe_amd.GSW(ring_d, n, n * ring_d.ell, seed=1)
+    og = oracle.GSW(ring_o, n, n * ring_o.ell)
+    big_n = ring_o.big_n(n)
+    assert _lib.lib().gsw_diag_bit_scale_mode(0, 31, 32 * ((n + 1 + 3) // 4 * 4)) == mode  # K slots: 32 per word, words in fours
+    rng = np.random.default_rng(n)
+    c1, c2 = _rand_compact(rng, ring_o, n, 4), _rand_compact(rng, ring_o, n, 4)
+    c1[0] = 0x7FFFFFFE  # p - 1: every bit but the lowest
+    c1[1] = 0x7FFFFFFE
+    c1[2, ::2] = 0x7FFFFFFE
+    # digits of 0x7F7F7F7F are +127 each, of 0x7F7F7F80 (taken as x - p) the most negative; a value scaled by 2^-c
+    # is its rotation, so rotations of those two give extreme digits in the scaled rows
+    extremes = np.array([0x7F7F7F7F, 0x7F7F7F80, 0x00808080, 0x7EFEFEFE], dtype=np.uint64)
+    rots = []
+    for v in extremes:
+        for c in range(4):
+            r = int(((int(v) << c) | (int(v) >> (31 - c))) & 0x7FFFFFFF)
+            rots.append(r if r < ring_o.q else r - ring_o.q)
+    rots = np.array(rots, dtype=np.uint32)
+    c2[0] = 0x7F7F7F7F
+    c2[1] = rots[rng.integers(0, len(rots), size=c2[1].shape)]
+    c2[2] = 0x7F7F7F80
+    d1 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c1)
+    d2 = tfhe_amd.Ciphertext.from_compact(gsw.engine, c2)
+    got = gsw.mult(d1, d2).to_compact()
+    assert gsw.last_combine() == 1  # the 32-bit recombination
+    got_nand = gsw.nand(d1, d2).to_compact()
+    rows = np.unique(np.concatenate([[0, 1, 30, 31, 255, 256, big_n - 1, big_n - 31, big_n - 32], rng.integers(0, big_n, size=8)]))
+    for b in range(4):
+        _sampled_rows_check(oracle, og, c1[b], c2[b], got[b], rows, f"mult[{b}] n={n}")
+        _sampled_rows_check(oracle, og, c1[b], c2[b], got_nand[b], rows[:5], f"nand[{b}] n={n}", oracle.FLAG_NAND)
