@@ -88,3 +88,24 @@ def test_repeated_dense_products_and_encryptions_are_identical(ring_name):
         again = gsw.encrypt_batch(pk, msgs, rbits=rbits).to_compact()
         bad = np.argwhere(again != first)
         assert len(bad) == 0, f"encrypt_batch, run {rep}: {len(bad)} entries differ from the first run, first at {bad[0].tolist()}"
+
+
+def test_seeded_keygen_and_encryption_repeat_exactly():
+    """Device key generation and seeded encryption (random bits drawn chunk by chunk on a second stream beside the
+    contraction) from the same seed, in fresh contexts: the same key and the same ciphertexts every time."""
+    import tfhe_amd
+
+    n, batch = 10, 3000  # several pipeline chunks of random bits
+    msgs = [b & 1 for b in range(batch)]
+    first = None
+    for rep in range(8):
+        gsw = tfhe_amd.GSW(tfhe_amd.Fp(), n, n * 31, seed=77)
+        sk, pk = gsw.keygen()
+        ct = gsw.encrypt_batch(pk, msgs).to_compact()
+        now = (np.asarray(sk.t).copy(), ct)
+        if first is None:
+            first = now
+            continue
+        assert np.array_equal(now[0], first[0]), f"run {rep}: another secret key from the same seed"
+        bad = np.argwhere(now[1] != first[1])
+        assert len(bad) == 0, f"run {rep}: {len(bad)} ciphertext entries differ from the first run, first at {bad[0].tolist()}"

@@ -181,12 +181,23 @@ class Ciphertext:
         if host.shape[1:] != (engine.big_n, engine.n + 1):
             raise ValueError(f"compact ciphertext must be {engine.big_n} x {engine.n + 1}, got {host.shape[1:]}")
         ct = cls(engine, host.shape[0])
+        if ct.batch * engine.compact_elems * 4 <= cls._BULK_BYTES and engine.compact_elems == engine.big_n * engine.ld:
+            # small entries: one copy of the padded image instead of a pitched copy per entry
+            padded = np.zeros((ct.batch, engine.big_n, engine.ld), dtype=np.uint32)
+            padded[:, :, : engine.n + 1] = host
+            ct.buf.upload(padded)
+            return ct
         for b in range(ct.batch):
             check(_lib.lib().gsw_upload_compact(engine.handle, ct.entry_ptr(b), host[b].ctypes.data))
         return ct
 
+    _BULK_BYTES = 256 << 20
+
     def to_compact(self) -> np.ndarray:
         e = self.engine
+        if self.batch > 1 and self.batch * e.compact_elems * 4 <= self._BULK_BYTES and e.compact_elems == e.big_n * e.ld:
+            raw = self.buf.download(np.uint32, self.batch * e.compact_elems).reshape(self.batch, e.big_n, e.ld)
+            return np.ascontiguousarray(raw[:, :, : e.n + 1])
         out = np.empty((self.batch, e.big_n, e.n + 1), dtype=np.uint32)
         for b in range(self.batch):
             check(_lib.lib().gsw_download_compact(e.handle, out[b].ctypes.data, self.entry_ptr(b)))
